@@ -1,0 +1,248 @@
+/*
+ * rt_amd.h -- C ABI of librt_amd.so: an MI355X (gfx950) replacement for the reference's
+ * path-tracing shader pass.
+ *
+ * The reference (grayleafy/RayTracing) has no plugin/FFI interface; the seam this library
+ * fills is the set of GL objects and uniforms that main.cpp:137-172 binds before
+ * RT_Screen::DrawScreen, plus the CPU BVH builder that feeds them.  Each entry point below
+ * names the reference code it stands in for.  File names are relative to the reference's
+ * source directory; "frag" is RayTracerFragmentShader.glsl.
+ *
+ * Conventions: every function returns 0 on success and a negative RT_E_* code on failure
+ * (the reference only prints errors: Shader.h:45-48, Model.h:60-64); rt_last_error() gives
+ * the message.  No exceptions cross this boundary.  Host arrays passed in are copied before
+ * the call returns and stay owned by the caller (the reference uploads and delete[]s its
+ * staging arrays, ObjectTexture.h:82,133).  A context belongs to one GPU; calls on one
+ * context must be serialised by the caller, distinct contexts may be used from distinct
+ * threads.  Images are W*H*3 floats, row 0 is the BOTTOM row (TexCoords.y ~ 0,
+ * RT_Screen.h:8-20): pixel (px,py) has TexCoords ((px+0.5)/W, (py+0.5)/H).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_INVALID (-1)   /* bad argument / size beyond a stated limit */
+#define RT_E_STATE (-2)     /* call order: no scene, no camera ... */
+#define RT_E_HIP (-3)       /* a HIP runtime call failed */
+#define RT_E_IO (-4)        /* file not found / parse error */
+#define RT_E_NOMEM (-5)
+
+#define RT_MAX_SPHERES 10   /* uniform Sphere sphere[10], frag:143 */
+#define RT_SOBOL_WORDS 512  /* uniform uint V[512], frag:81 */
+#define RT_MAX_BOUNCES 8    /* 16 Sobol dimensions / 2 per bounce, frag:100-104 */
+
+/* class Triangle, BVH.h:26-33 (144 bytes, same field order). */
+typedef struct RtTriangle {
+    float v[3][3];
+    float n[3][3];
+    float tex[3][2];
+    float ka[3], kd[3], ks[3];
+    float center[3];
+} RtTriangle;
+
+/* class LinearBVHNode, BVH.h:99-105 (36 bytes, same field order). */
+typedef struct RtLinearBVHNode {
+    float minBound[3], maxBound[3];
+    int32_t triangleNum;
+    int32_t offsetOrRc;
+    int32_t axis;
+} RtLinearBVHNode;
+
+/* class Sphere, Scene.h:27-44; uniform struct Sphere, frag:135-142. */
+typedef struct RtSphere {
+    float center[3];
+    float radius;
+    float albedo[3];
+    float specularRate;     /* diffuse threshold, frag:586 */
+    float refractionRate;   /* mirror threshold, frag:594 */
+    float roughness;        /* carried, unused (frag:543,554) */
+} RtSphere;
+
+/* uniform struct Camera, frag:115-124, filled at main.cpp:156-163. */
+typedef struct RtCamera {
+    float camPos[3];
+    float front[3];
+    float right[3];
+    float up[3];
+    float halfH;
+    float halfW;
+    float leftbottom[3];
+    int32_t LoopNum;        /* ignored by rt_set_camera; frames are numbered by rt_render_frames */
+} RtCamera;
+
+/* Work counters of the render calls since the last rt_reset (all frames, all pixels). */
+typedef struct RtStats {
+    uint64_t rays;          /* closest-hit queries traced: camera ray + one per scatter; a ray
+                               that already missed is not traced again (the reference re-traces
+                               it, frag:655-670, with no effect on the image) */
+    uint64_t node_tests;    /* bounding boxes tested (IntersectBound, frag:309-331) */
+    uint64_t tri_tests;     /* triangles tested (hitTriangle, frag:255-278) */
+    uint64_t tri_hits;      /* rays whose closest BVH hit was a triangle (frag:457) */
+    uint64_t frames;        /* frames rendered */
+} RtStats;
+
+/* Render options; rt_default_options() gives the reference's behaviour. */
+typedef struct RtOptions {
+    int32_t max_bounces;    /* loop bound of shading(), 4 in the reference (frag:624); <= 8 */
+    int32_t pipeline;       /* RT_PIPELINE_* */
+    int32_t cull;           /* 1: skip boxes that provably cannot hold a closer hit (same image);
+                               0: visit exactly the boxes the reference visits */
+    int32_t count_work;     /* 1: maintain node_tests/tri_tests/tri_hits (slower kernels) */
+} RtOptions;
+#define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
+#define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */
+
+typedef struct RtContext RtContext;
+typedef struct RtScene RtScene;     /* host-side scene assembly (Scene.h) */
+
+/* ---------------------------------------------------------------- host side, no GPU */
+
+/* BVHTree::build + split + buildLinerTree + addLinearNode, BVH.h:117-287.
+ * tris[0..n) hold v/n/tex/ka/kd/ks in scene order (mesh order, then index order,
+ * BVH.h:120-135); `center` is computed here (BVH.h:36-39).  On return tris is permuted in
+ * place exactly as the reference's nth_element recursion permutes it and nodes[0..2n-1)
+ * holds the pre-order tree: leaves have triangleNum 1, offsetOrRc = triangle index, axis -1;
+ * interior nodes have offsetOrRc = right child, left child = own index + 1.  The selection
+ * step reproduces libstdc++'s std::nth_element permutation without calling it.
+ * node_capacity must be >= 2n-1.  *node_count receives 2n-1.  n == 0 is RT_E_INVALID (the
+ * reference dereferences triangles[0], BVH.h:141). */
+int rt_bvh_build(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity,
+                 int64_t *node_count);
+
+/* Texture geometry of getTexture(), ObjectTexture.h:79-80 and 138-139: a count*per float
+ * array stored in a (x*per) x y R32F texture. */
+int rt_texture_dims(int64_t count, int per, int *x, int *y);
+/* ObjectTexture.h:82-115: out has x*y*33 floats, 33 per triangle (v,n,uv per vertex, ka, kd,
+ * ks); texels after the last triangle are zero (uninitialised in the reference). */
+int rt_pack_triangle_texture(const RtTriangle *tris, int64_t n, float *out, int x, int y);
+/* ObjectTexture.h:140-161: out has x*y*9 floats per node: max xyz, min xyz, triangleNum,
+ * offsetOrRc, axis (integers stored as floats). */
+int rt_pack_bvh_texture(const RtLinearBVHNode *nodes, int64_t m, float *out, int x, int y);
+
+/* uint V[16*32], sobol.h:8-25 (= v_matrix.txt): regenerated from the Joe-Kuo primitive
+ * polynomials and initial direction numbers of dimensions 1-16. */
+int rt_sobol_default_table(uint32_t v[RT_SOBOL_WORDS]);
+/* grayCode / sobol, sobol.h:37-50 (CPU twins of frag:84-97). */
+uint32_t rt_gray_code(uint32_t i);
+float rt_sobol(const uint32_t v[RT_SOBOL_WORDS], uint32_t d, uint32_t i);
+
+/* Camera::Camera + updateCameraVectors, Camera.h:18-46: yaw/pitch/fov in degrees,
+ * halfH = tan(radians(fov)), halfW = halfH*W/H, leftbottom = front - halfW*right - halfH*up.
+ * rt_camera_default = position (0,2,5), yaw -90, pitch 0, fov 45. */
+int rt_camera_from_angles(RtCamera *out, const float pos[3], float yaw_deg, float pitch_deg,
+                          float fov_deg, int width, int height);
+int rt_camera_default(RtCamera *out, int width, int height);
+
+/* Replaces CPURandomInit/GetCPURandom, Tool.h:8-14, which seed from time(): an explicit
+ * 32-bit generator.  *state is advanced; returns 874264.0f * (u + 1.0f), u in [0,1), the
+ * value main.cpp:149 feeds to the `randOrigin` uniform. */
+float rt_rand_origin(uint32_t *state);
+
+/* Scene assembly, Scene.h:46-90 + Model.h:54-182 + BVH.h:120-135. */
+int rt_scene_create(RtScene **out);
+void rt_scene_destroy(RtScene *scene);
+/* Model(path) then Scene::pushModel(model, scale, translation), main.cpp:103-107: Wavefront
+ * OBJ + MTL; one mesh per object/material group in file order, polygons fan-triangulated,
+ * per-mesh Ka/Kd/Ks; Position = Position*scale + translation (Scene.h:57-60). */
+int rt_scene_push_obj(RtScene *scene, const char *obj_path, const float scale[3],
+                      const float translation[3]);
+/* Same transform applied to caller-provided triangles (v/n/tex/ka/kd/ks used). */
+int rt_scene_push_triangles(RtScene *scene, const RtTriangle *tris, int64_t n,
+                            const float scale[3], const float translation[3]);
+/* Scene::pushSphere, Scene.h:67-69. */
+int rt_scene_push_sphere(RtScene *scene, const RtSphere *sphere);
+/* The scene of main.cpp:103-110 built procedurally (room + cube + two spheres): the same 32
+ * triangles, in the same order, that loading objects/room.obj and objects/cube.obj gives. */
+int rt_scene_push_demo(RtScene *scene);
+/* Synthetic benchmark geometry.  kind 0: the demo room (20 triangles, light included) around
+ * `copies` displaced icospheres of 20*4^level triangles (seeded radial sinusoid);
+ * kind 1: room scaled x3 with a grid of cols x rows tessellated columns of 2*level*level
+ * triangles cycling diffuse / mirror / glass, plus the two demo spheres. */
+int rt_scene_push_synthetic(RtScene *scene, int kind, int level, int copies, uint32_t seed);
+int64_t rt_scene_triangle_count(const RtScene *scene);
+int rt_scene_sphere_count(const RtScene *scene);
+/* The vector<Triangle> as it stands before BVHTree::split (BVH.h:120-135). */
+int rt_scene_get_triangles(const RtScene *scene, RtTriangle *out, int64_t capacity);
+int rt_scene_get_spheres(const RtScene *scene, RtSphere *out, int capacity);
+
+/* ---------------------------------------------------------------- device side */
+
+/* Creates a context on HIP device `device` for a W x H image (the FBO pair of
+ * RT_Screen.h:53-125, created once at a fixed size, main.cpp:91).  The Sobol table defaults
+ * to rt_sobol_default_table (setSobol, main.cpp:98). */
+int rt_create(RtContext **out, int width, int height, int device);
+void rt_destroy(RtContext *ctx);
+/* HIP stream (hipStream_t) the context launches on; NULL = the default stream. */
+int rt_set_stream(RtContext *ctx, void *hip_stream);
+int rt_default_options(RtOptions *out);
+int rt_set_options(RtContext *ctx, const RtOptions *opt);
+
+/* getTexture(tree, shader, objTex), main.cpp:120 / ObjectTexture.h:69-182: takes the
+ * builder's output in its in-memory layouts and converts it to the device layout.  The tree
+ * must be the reference's shape (pre-order, left child = index+1, one triangle per leaf). */
+int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n,
+                    const RtLinearBVHNode *nodes, int64_t m);
+/* Same, from the flat arrays the reference puts into texTriangle / texBVH (33 resp. 9
+ * floats per record, records contiguous). */
+int rt_scene_upload_textures(RtContext *ctx, const float *tex_triangle, int64_t n,
+                             const float *tex_bvh, int64_t m);
+/* setSobol, sobol.h:27-34. */
+int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]);
+/* Scene::setSphere, Scene.h:71-85 (count <= 10). */
+int rt_set_spheres(RtContext *ctx, const RtSphere *spheres, int count);
+/* The camera.* uniforms of main.cpp:156-162. */
+int rt_set_camera(RtContext *ctx, const RtCamera *cam);
+
+/* The per-frame part of the main loop, main.cpp:137-172: renders `count` frames with
+ * camera.LoopNum = first_loopnum .. first_loopnum+count-1 and randOrigin[i] for frame i,
+ * adding each frame's sample to the accumulators.  Asynchronous on the context's stream. */
+int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *rand_origin);
+/* Camera::LoopNum = 0 (Camera.h:45): clears the accumulators and the counters. */
+int rt_reset(RtContext *ctx);
+int rt_synchronize(RtContext *ctx);
+
+/* The running mean the reference keeps in its FBO (frag:697, fp32 here instead of the
+ * reference's 8-bit texture): mean_N = sample/N + mean_{N-1}*(N-1)/N, valid when frames were
+ * rendered in order from LoopNum 1. */
+int rt_read_mean(RtContext *ctx, float *rgb);
+/* Plain fp32 sum of all samples since rt_reset (what a multi-GPU reduce adds up). */
+int rt_read_sum(RtContext *ctx, float *rgb);
+/* Device address of the W*H*3 fp32 sum buffer (for a caller-side collective). */
+int rt_sum_device_ptr(RtContext *ctx, void **dev_ptr);
+/* Accumulate sums into caller-owned device memory (W*H*3 floats) instead; NULL restores the
+ * internal buffer.  The buffer is not cleared by this call. */
+int rt_bind_sum_buffer(RtContext *ctx, float *dev_ptr);
+
+int rt_get_stats(RtContext *ctx, RtStats *out);
+/* Device time of the traversal ("extend") kernel launches since the last rt_reset, measured
+ * with HIP events on the context's stream.  Synchronises. */
+int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches);
+
+/* The traversal loop of hitBVH alone (frag:373-456) for caller-supplied rays: origins/dirs are
+ * n*3 floats; t_out[i] = ray.hitMin of the kept triangle (its t - 1e-5) or -1 for a miss;
+ * id_out[i] = that triangle's index in the uploaded order or -1.  Synchronous; for tests and
+ * tools. */
+int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64_t n,
+                  float *t_out, int32_t *id_out);
+
+/* Diagnostics with no counterpart in the reference, used by the parity tests.
+ * rt_selftest_nth_element: the builder's selection routine alone (keys with ids carried
+ * along), to compare its permutation with std::nth_element's (BVH.h:222).
+ * rt_selftest_arith: the device's a/b, sqrt|a|, fma(a,b,a), and sin/cos of |b| mod 2*pi, five
+ * floats per element, to compare with the host's arithmetic. */
+int rt_selftest_nth_element(float *keys, int32_t *ids, int64_t n, int64_t nth);
+int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out);
+
+const char *rt_last_error(const RtContext *ctx);    /* ctx may be NULL: last error of a call without a context */
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,336 @@
+"""ctypes binding of librt_amd.so plus a thin host-side mirror of the reference's main loop.
+
+The compute path is the HIP library only: importing this package raises if the library is
+missing, and nothing here falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python raytracing_amd/build.py` "
+        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+
+lib = C.CDLL(LIB_PATH)
+
+RT_MAX_SPHERES = 10
+RT_SOBOL_WORDS = 512
+RT_MAX_BOUNCES = 8
+PIPELINE_WAVEFRONT = 0
+PIPELINE_MEGAKERNEL = 1
+
+# numpy views of the C structs of include/rt_amd.h
+TRIANGLE_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("n", "<f4", (3, 3)), ("tex", "<f4", (3, 2)),
+                           ("ka", "<f4", 3), ("kd", "<f4", 3), ("ks", "<f4", 3), ("center", "<f4", 3)])
+NODE_DTYPE = np.dtype([("minBound", "<f4", 3), ("maxBound", "<f4", 3),
+                       ("triangleNum", "<i4"), ("offsetOrRc", "<i4"), ("axis", "<i4")])
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("albedo", "<f4", 3),
+                         ("specularRate", "<f4"), ("refractionRate", "<f4"), ("roughness", "<f4")])
+CAMERA_DTYPE = np.dtype([("camPos", "<f4", 3), ("front", "<f4", 3), ("right", "<f4", 3), ("up", "<f4", 3),
+                         ("halfH", "<f4"), ("halfW", "<f4"), ("leftbottom", "<f4", 3), ("LoopNum", "<i4")])
+assert TRIANGLE_DTYPE.itemsize == 144 and NODE_DTYPE.itemsize == 36
+assert SPHERE_DTYPE.itemsize == 40 and CAMERA_DTYPE.itemsize == 72
+
+
+class RtStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("tri_hits", C.c_uint64), ("frames", C.c_uint64)]
+
+
+class RtOptions(C.Structure):
+    _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
+                ("count_work", C.c_int32)]
+
+
+_vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
+_PROTOS = {
+    "rt_bvh_build": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "rt_texture_dims": (_int, [_i64, _int, C.POINTER(_int), C.POINTER(_int)]),
+    "rt_pack_triangle_texture": (_int, [_vp, _i64, _vp, _int, _int]),
+    "rt_pack_bvh_texture": (_int, [_vp, _i64, _vp, _int, _int]),
+    "rt_sobol_default_table": (_int, [_vp]),
+    "rt_gray_code": (C.c_uint32, [C.c_uint32]),
+    "rt_sobol": (C.c_float, [_vp, C.c_uint32, C.c_uint32]),
+    "rt_camera_from_angles": (_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, _int, _int]),
+    "rt_camera_default": (_int, [_vp, _int, _int]),
+    "rt_rand_origin": (C.c_float, [C.POINTER(C.c_uint32)]),
+    "rt_scene_create": (_int, [C.POINTER(_vp)]),
+    "rt_scene_destroy": (None, [_vp]),
+    "rt_scene_push_obj": (_int, [_vp, C.c_char_p, _vp, _vp]),
+    "rt_scene_push_triangles": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rt_scene_push_sphere": (_int, [_vp, _vp]),
+    "rt_scene_push_demo": (_int, [_vp]),
+    "rt_scene_push_synthetic": (_int, [_vp, _int, _int, _int, C.c_uint32]),
+    "rt_scene_triangle_count": (_i64, [_vp]),
+    "rt_scene_sphere_count": (_int, [_vp]),
+    "rt_scene_get_triangles": (_int, [_vp, _vp, _i64]),
+    "rt_scene_get_spheres": (_int, [_vp, _vp, _int]),
+    "rt_create": (_int, [C.POINTER(_vp), _int, _int, _int]),
+    "rt_destroy": (None, [_vp]),
+    "rt_set_stream": (_int, [_vp, _vp]),
+    "rt_default_options": (_int, [C.POINTER(RtOptions)]),
+    "rt_set_options": (_int, [_vp, C.POINTER(RtOptions)]),
+    "rt_scene_upload": (_int, [_vp, _vp, _i64, _vp, _i64]),
+    "rt_scene_upload_textures": (_int, [_vp, _vp, _i64, _vp, _i64]),
+    "rt_set_sobol": (_int, [_vp, _vp]),
+    "rt_set_spheres": (_int, [_vp, _vp, _int]),
+    "rt_set_camera": (_int, [_vp, _vp]),
+    "rt_render_frames": (_int, [_vp, _int, _int, _vp]),
+    "rt_reset": (_int, [_vp]),
+    "rt_synchronize": (_int, [_vp]),
+    "rt_read_mean": (_int, [_vp, _vp]),
+    "rt_read_sum": (_int, [_vp, _vp]),
+    "rt_sum_device_ptr": (_int, [_vp, C.POINTER(_vp)]),
+    "rt_bind_sum_buffer": (_int, [_vp, _vp]),
+    "rt_get_stats": (_int, [_vp, C.POINTER(RtStats)]),
+    "rt_get_kernel_time": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "rt_trace_rays": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "rt_selftest_nth_element": (_int, [_vp, _vp, _i64, _i64]),
+    "rt_selftest_arith": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "rt_last_error": (C.c_char_p, [_vp]),
+    "rt_version": (C.c_char_p, []),
+}
+for _name, (_res, _args) in _PROTOS.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = lib.rt_last_error(ctx)
+        raise RtError(f"rt_amd error {rc}: {msg.decode() if msg else ''}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ host-side helpers
+
+def sobol_default_table():
+    v = np.zeros(RT_SOBOL_WORDS, dtype=np.uint32)
+    _check(lib.rt_sobol_default_table(_ptr(v)))
+    return v
+
+
+def camera_default(width, height):
+    cam = np.zeros(1, dtype=CAMERA_DTYPE)
+    _check(lib.rt_camera_default(_ptr(cam), width, height))
+    return cam
+
+
+def camera_from_angles(pos, yaw, pitch, fov, width, height):
+    cam = np.zeros(1, dtype=CAMERA_DTYPE)
+    p = np.asarray(pos, dtype=np.float32)
+    _check(lib.rt_camera_from_angles(_ptr(cam), _ptr(p), yaw, pitch, fov, width, height))
+    return cam
+
+
+def rand_origins(seed, count):
+    """The explicit stand-in for the reference's time-seeded rand(): count randOrigin values."""
+    state = C.c_uint32(seed)
+    return np.array([lib.rt_rand_origin(C.byref(state)) for _ in range(count)], dtype=np.float32)
+
+
+def bvh_build(tris):
+    """Returns (permuted triangles, nodes); `tris` is not modified."""
+    tris = np.ascontiguousarray(tris, dtype=TRIANGLE_DTYPE).copy()
+    n = tris.shape[0]
+    nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
+    cnt = C.c_int64(0)
+    _check(lib.rt_bvh_build(_ptr(tris), n, _ptr(nodes), nodes.shape[0], C.byref(cnt)))
+    return tris, nodes[:cnt.value]
+
+
+def pack_textures(tris, nodes):
+    """The reference's two R32F textures as flat arrays: (texTriangle, width, texBVH, width)."""
+    x, y = C.c_int(), C.c_int()
+    _check(lib.rt_texture_dims(tris.shape[0], 33, C.byref(x), C.byref(y)))
+    tt = np.zeros(x.value * y.value * 33, dtype=np.float32)
+    _check(lib.rt_pack_triangle_texture(_ptr(tris), tris.shape[0], _ptr(tt), x.value, y.value))
+    tw = x.value * 33
+    _check(lib.rt_texture_dims(nodes.shape[0], 9, C.byref(x), C.byref(y)))
+    tb = np.zeros(x.value * y.value * 9, dtype=np.float32)
+    _check(lib.rt_pack_bvh_texture(_ptr(nodes), nodes.shape[0], _ptr(tb), x.value, y.value))
+    return tt, tw, tb, x.value * 9
+
+
+class Scene:
+    """Host-side scene assembly (the reference's Scene + Model loading)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib.rt_scene_create(C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    def push_obj(self, path, scale=(1, 1, 1), translation=(0, 0, 0)):
+        s = np.asarray(scale, dtype=np.float32)
+        t = np.asarray(translation, dtype=np.float32)
+        _check(lib.rt_scene_push_obj(self._h, os.fsencode(path), _ptr(s), _ptr(t)))
+
+    def push_triangles(self, tris, scale=(1, 1, 1), translation=(0, 0, 0)):
+        tris = np.ascontiguousarray(tris, dtype=TRIANGLE_DTYPE)
+        s = np.asarray(scale, dtype=np.float32)
+        t = np.asarray(translation, dtype=np.float32)
+        _check(lib.rt_scene_push_triangles(self._h, _ptr(tris), tris.shape[0], _ptr(s), _ptr(t)))
+
+    def push_sphere(self, center, radius, albedo, specular_rate, refraction_rate, roughness=0.0):
+        s = np.zeros(1, dtype=SPHERE_DTYPE)
+        s["center"] = center
+        s["radius"] = radius
+        s["albedo"] = albedo
+        s["specularRate"] = specular_rate
+        s["refractionRate"] = refraction_rate
+        s["roughness"] = roughness
+        _check(lib.rt_scene_push_sphere(self._h, _ptr(s)))
+
+    def push_demo(self):
+        _check(lib.rt_scene_push_demo(self._h))
+
+    def push_synthetic(self, kind, level, copies=1, seed=12345):
+        _check(lib.rt_scene_push_synthetic(self._h, kind, level, copies, seed))
+
+    def triangles(self):
+        n = lib.rt_scene_triangle_count(self._h)
+        out = np.zeros(n, dtype=TRIANGLE_DTYPE)
+        if n:
+            _check(lib.rt_scene_get_triangles(self._h, _ptr(out), n))
+        return out
+
+    def spheres(self):
+        n = lib.rt_scene_sphere_count(self._h)
+        out = np.zeros(n, dtype=SPHERE_DTYPE)
+        if n:
+            _check(lib.rt_scene_get_spheres(self._h, _ptr(out), n))
+        return out
+
+
+# ------------------------------------------------------------------ device side
+
+class Renderer:
+    """One GPU context: the shader pass of the reference's main loop."""
+
+    def __init__(self, width, height, device=0):
+        h = C.c_void_p()
+        _check(lib.rt_create(C.byref(h), width, height, device))
+        self._h = h
+        self.width, self.height = width, height
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
+
+    def set_options(self, max_bounces=4, pipeline=PIPELINE_WAVEFRONT, cull=True, count_work=False):
+        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work))
+        _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
+
+    def upload(self, tris, nodes):
+        tris = np.ascontiguousarray(tris, dtype=TRIANGLE_DTYPE)
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        _check(lib.rt_scene_upload(self._h, _ptr(tris), tris.shape[0], _ptr(nodes), nodes.shape[0]), self._h)
+
+    def upload_textures(self, tex_triangle, n, tex_bvh, m):
+        tt = np.ascontiguousarray(tex_triangle, dtype=np.float32)
+        tb = np.ascontiguousarray(tex_bvh, dtype=np.float32)
+        _check(lib.rt_scene_upload_textures(self._h, _ptr(tt), n, _ptr(tb), m), self._h)
+
+    def set_sobol(self, v):
+        v = np.ascontiguousarray(v, dtype=np.uint32)
+        assert v.shape[0] == RT_SOBOL_WORDS
+        _check(lib.rt_set_sobol(self._h, _ptr(v)), self._h)
+
+    def set_spheres(self, spheres):
+        s = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        _check(lib.rt_set_spheres(self._h, _ptr(s), s.shape[0]), self._h)
+
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(cam, dtype=CAMERA_DTYPE)
+        _check(lib.rt_set_camera(self._h, _ptr(cam)), self._h)
+
+    def render(self, first_loopnum, rand_origin):
+        r = np.ascontiguousarray(rand_origin, dtype=np.float32)
+        _check(lib.rt_render_frames(self._h, first_loopnum, r.shape[0], _ptr(r)), self._h)
+
+    def reset(self):
+        _check(lib.rt_reset(self._h), self._h)
+
+    def synchronize(self):
+        _check(lib.rt_synchronize(self._h), self._h)
+
+    def read_mean(self):
+        out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        _check(lib.rt_read_mean(self._h, _ptr(out)), self._h)
+        return out
+
+    def read_sum(self):
+        out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        _check(lib.rt_read_sum(self._h, _ptr(out)), self._h)
+        return out
+
+    def bind_sum_buffer(self, dev_ptr):
+        _check(lib.rt_bind_sum_buffer(self._h, C.c_void_p(dev_ptr)), self._h)
+
+    def sum_device_ptr(self):
+        p = C.c_void_p()
+        _check(lib.rt_sum_device_ptr(self._h, C.byref(p)), self._h)
+        return p.value
+
+    def stats(self):
+        s = RtStats()
+        _check(lib.rt_get_stats(self._h, C.byref(s)), self._h)
+        return {k: getattr(s, k) for k, _ in RtStats._fields_}
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib.rt_get_kernel_time(self._h, C.byref(ms), C.byref(n)), self._h)
+        return ms.value, n.value
+
+    def trace_rays(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        t = np.zeros(o.shape[0], dtype=np.float32)
+        ids = np.zeros(o.shape[0], dtype=np.int32)
+        _check(lib.rt_trace_rays(self._h, _ptr(o), _ptr(d), o.shape[0], _ptr(t), _ptr(ids)), self._h)
+        return t, ids
+
+    def selftest_arith(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.zeros((a.shape[0], 5), dtype=np.float32)
+        _check(lib.rt_selftest_arith(self._h, _ptr(a), _ptr(b), a.shape[0], _ptr(out)), self._h)
+        return out
+
+
+def make_renderer(scene, width, height, device=0, camera=None, **options):
+    """main.cpp:101-121 in one call: build the BVH of `scene`, upload it, set camera and spheres."""
+    tris, nodes = bvh_build(scene.triangles())
+    r = Renderer(width, height, device)
+    r.upload(tris, nodes)
+    r.set_spheres(scene.spheres())
+    r.set_camera(camera if camera is not None else camera_default(width, height))
+    if options:
+        r.set_options(**options)
+    return r

@@ -1,0 +1,1057 @@
+// HIP kernels (gfx950) and the device half of the C ABI declared in include/rt_amd.h.
+// Compile with -ffp-contract=off: every fused multiply-add is written out (rt_math.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+#include "rt_kernels.h"
+
+using namespace rtd;
+using rtm::vec3;
+
+// Sobol direction numbers (uniform uint V[512], frag:81) live in constant memory: every lane
+// of a wave reads the same word, which the scalar unit serves.
+__constant__ uint32_t c_sobolV[RT_SOBOL_WORDS];
+
+namespace {
+
+constexpr int BLOCK = 256;          // 4 waves
+constexpr float HIT_MIN_INIT = 100000.0f;   // frag:633,689
+
+// ------------------------------------------------------------------ small device helpers
+
+__device__ __forceinline__ float rand01(uint32_t &wseed) {     // frag:36-47
+    wseed = rtm::wang_step(wseed);
+    return (float)wseed * (1.0f / 4294967296.0f);
+}
+
+// frag:84-104 for one bounce: dims 2b and 2b+1 of frame `loopNum`.  loopNum and b are wave
+// uniform, so this runs on the scalar unit out of constant memory.
+__device__ __forceinline__ void sobol_pair(uint32_t loopNum, uint32_t b, float &u, float &v) {
+    uint32_t g = loopNum ^ (loopNum >> 1);
+    uint32_t r0 = 0u, r1 = 0u;
+    const uint32_t base = b * 64u;
+    for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
+        if (g & 1u) {
+            r0 ^= c_sobolV[base + j];
+            r1 ^= c_sobolV[base + 32u + j];
+        }
+    u = (float)r0 * (1.0f / 4294967296.0f);
+    v = (float)r1 * (1.0f / 4294967296.0f);
+}
+
+// frag:59-77
+__device__ __forceinline__ void cranley_patterson(float uvx, float uvy, int width, int height, float &px, float &py) {
+    const uint32_t X = (uint32_t)(rtm::madd(rtm::madd(uvx, 2.0f, -1.0f), 0.5f, 0.5f) * (float)width);
+    const uint32_t Y = (uint32_t)(rtm::madd(rtm::madd(uvy, 2.0f, -1.0f), 0.5f, 0.5f) * (float)height);
+    uint32_t pseed = (X * 1973u + Y * 9277u + (uint32_t)(114514 / 1919) * 26699u) | 1u;
+    pseed = rtm::wang_step(pseed);
+    const float u = (float)pseed / 4294967296.0f;
+    pseed = rtm::wang_step(pseed);
+    const float v = (float)pseed / 4294967296.0f;
+    float x = px + u;
+    if (x > 1.0f) x -= 1.0f;
+    if (x < 0.0f) x += 1.0f;
+    float y = py + v;
+    if (y > 1.0f) y -= 1.0f;
+    if (y < 0.0f) y += 1.0f;
+    px = x; py = y;
+}
+
+// IntersectBound, frag:309-331, evaluated without early exits (the values computed after a
+// failed test are unused, so the outcome is the same).  near[] receives the three entry
+// distances for the conservative culling bound.
+__device__ __forceinline__ bool slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                          const vec3 o, const vec3 inv, bool nx, bool ny, bool nz,
+                                          float &nearx, float &neary, float &nearz) {
+    float tMin = ((nx ? mxx : mnx) - o.x) * inv.x;
+    float tMax = ((nx ? mnx : mxx) - o.x) * inv.x;
+    const float tyMin = ((ny ? mxy : mny) - o.y) * inv.y;
+    const float tyMax = ((ny ? mny : mxy) - o.y) * inv.y;
+    nearx = tMin; neary = tyMin;
+    const bool fail1 = (tMin > tyMax) || (tyMin > tMax);
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    const float tzMin = ((nz ? mxz : mnz) - o.z) * inv.z;
+    const float tzMax = ((nz ? mnz : mxz) - o.z) * inv.z;
+    nearz = tzMin;
+    const bool fail2 = (tMin > tzMax) || (tzMin > tMax);
+    if (tzMax < tMax) tMax = tzMax;
+    return !fail1 && !fail2 && (tMax > 0.0f);
+}
+
+// hitTriangle, frag:255-278, with N and D taken from the triangle record.
+__device__ __forceinline__ float triangle_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                               const vec3 o, const vec3 d) {
+    const vec3 v0 = rtm::mk(q0.x, q0.y, q0.z);
+    const vec3 v1 = rtm::mk(q0.w, q1.x, q1.y);
+    const vec3 v2 = rtm::mk(q1.z, q1.w, q2.x);
+    const vec3 N = rtm::mk(q2.y, q2.z, q2.w);
+    const float D = q3.x;
+    const float nd = rtm::dot(N, d);
+    if (nd == 0.0f) return -1.0f;
+    const float t = -(rtm::dot(N, o) + D) / nd;
+    if (t < 0.0f) return -1.0f;
+    const vec3 pHit = rtm::along(o, t, d);
+    if (rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pHit, v0))) < 0.0f) return -1.0f;
+    if (rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pHit, v1))) < 0.0f) return -1.0f;
+    if (rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pHit, v2))) < 0.0f) return -1.0f;
+    return t - 0.00001f;
+}
+
+// The traversal loop of hitBVH, frag:380-421.  Visits children in the reference's order
+// (near child by dirIsNeg[axis], far child deferred on a LIFO stack) and keeps the closest
+// hit with the same strict comparison, so ties resolve as in the reference.
+// stack: this lane's LDS column, entry i at stack[i*stride].
+// CULL: additionally skip a box when a lower bound of its entry distance, computed against
+// the box grown by eps, lies beyond the closest hit so far; no triangle in such a box can
+// pass `dis_t < ray.hitMin` (frag:396), so the result is unchanged.
+template <bool CULL, bool COUNT>
+__device__ __forceinline__ void closest_triangle(const SceneD &S, const vec3 o, const vec3 d,
+                                                 uint32_t *stack, const int stride,
+                                                 float &tOut, uint32_t &triOut,
+                                                 uint32_t &nNode, uint32_t &nTri) {
+    float hitMin = HIT_MIN_INIT;
+    uint32_t best = REF_NONE;
+    const vec3 inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);      // frag:376
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;  // frag:378
+    float ex = 0.0f, ey = 0.0f, ez = 0.0f, hitCull = 0.0f;
+    if (CULL) {
+        const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+        const float eps = rtm::madd(oM, 1.0f / 1024.0f, S.cullEps);
+        ex = eps * fabsf(inv.x); ey = eps * fabsf(inv.y); ez = eps * fabsf(inv.z);
+        hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+    }
+    uint32_t cur = S.rootRef;
+    if (cur != REF_NONE) {
+        float a, b, c;
+        const bool pass = slab_test(S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2],
+                                    o, inv, nx, ny, nz, a, b, c);
+        if (COUNT) nNode++;
+        if (!pass) cur = REF_NONE;
+    }
+    int sp = 0;
+    while (cur != REF_NONE) {
+        if (cur & LEAF_BIT) {
+            const uint32_t ti = cur & ~LEAF_BIT;
+            const float4 *rec = S.tris + (size_t)ti * 4;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            const float dis = triangle_test(q0, q1, q2, q3, o, d);
+            if (COUNT) nTri++;
+            if (dis > 0.0f && dis < hitMin) {           // frag:396
+                hitMin = dis;
+                best = ti;
+                if (CULL) hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+            }
+            cur = REF_NONE;
+            if (sp > 0) cur = stack[(--sp) * stride];
+        } else {
+            const float4 *rec = S.nodes + (size_t)cur * 4;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            float lnx, lny, lnz, rnx, rny, rnz;
+            bool passL = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, lnx, lny, lnz);
+            bool passR = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, nx, ny, nz, rnx, rny, rnz);
+            if (COUNT) nNode += 2;
+            if (CULL) {
+                const float lb = fmaxf(lnx - ex, fmaxf(lny - ey, lnz - ez));
+                const float rb = fmaxf(rnx - ex, fmaxf(rny - ey, rnz - ez));
+                if (lb > hitCull) passL = false;
+                if (rb > hitCull) passR = false;
+            }
+            const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+            const bool negAxis = (axis == 0u) ? nx : ((axis == 1u) ? ny : nz);      // frag:407
+            const uint32_t nearRef = negAxis ? right : left;
+            const uint32_t farRef = negAxis ? left : right;
+            const bool nearPass = negAxis ? passR : passL;
+            const bool farPass = negAxis ? passL : passR;
+            if (nearPass) {
+                cur = nearRef;
+                if (farPass) stack[(sp++) * stride] = farRef;
+            } else if (farPass) {
+                cur = farRef;
+            } else {
+                cur = REF_NONE;
+                if (sp > 0) cur = stack[(--sp) * stride];
+            }
+        }
+    }
+    tOut = hitMin;
+    triOut = best;
+}
+
+struct Path {
+    vec3 o, d, thr;
+    uint32_t seed;
+};
+
+// hitSphere, frag:281-293
+__device__ __forceinline__ float sphere_test(const RtSphere &s, const vec3 o, const vec3 d) {
+    const vec3 oc = rtm::sub(o, rtm::mk(s.center[0], s.center[1], s.center[2]));
+    const float a = rtm::dot(d, d);
+    const float b = 2.0f * rtm::dot(oc, d);
+    const float c = rtm::madd(-s.radius, s.radius, rtm::dot(oc, oc));
+    const float disc = rtm::madd(b, b, -((4.0f * a) * c));
+    if (disc > 0.0f) {
+        const float dis = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        return (dis > 0.0f) ? dis : -1.0f;
+    }
+    return -1.0f;
+}
+
+// Everything the shader does with a ray after the BVH loop: the rest of hitBVH
+// (frag:457-488), the sphere loop of hitWorld (frag:570-614), the material switch of
+// shading (frag:631-670), the 4*pi scaling (frag:672-673) and the Russian-roulette draw that
+// opens the next iteration (frag:625-630).  Returns true when the path goes on (p holds the
+// next ray); otherwise `sample` is the frame's radiance for the pixel.
+__device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
+                                          int bounce, uint32_t loopNum, float uvx, float uvy, vec3 &sample) {
+    sample = rtm::mk(0.0f, 0.0f, 0.0f);
+    bool hit = false;
+    float hitMin = HIT_MIN_INIT;
+    vec3 pos = rtm::mk(0, 0, 0), nrm = rtm::mk(0, 0, 0), albedo = rtm::mk(0, 0, 0);
+    int material = -1;
+    float refraction = 1.0f;
+    if (tri != REF_NONE) {
+        const float4 *rec = S.tris + (size_t)tri * 4;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        const vec3 v0 = rtm::mk(q0.x, q0.y, q0.z), v1 = rtm::mk(q0.w, q1.x, q1.y), v2 = rtm::mk(q1.z, q1.w, q2.x);
+        pos = rtm::along(p.o, tTri, p.d);                                       // frag:458
+        nrm = rtm::normalize(rtm::cross(rtm::sub(v2, v0), rtm::sub(v1, v0)));   // frag:296-300
+        if (rtm::dot(nrm, p.d) > 0.0f) nrm = rtm::neg(nrm);
+        const float temp = rand01(p.seed);                                      // frag:462
+        const float4 *m = S.mats + (size_t)tri * 3;
+        const float4 m0 = m[0], m1 = m[1], m2 = m[2];
+        const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
+        const float ksx = m1.z, ksy = m1.w;
+        if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }             // length(ka) > 0
+        else if (temp < ksx) { material = 1; albedo = kd; }
+        else if (temp < ksy) { material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f); }
+        else { material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f); refraction = 1.5f; }
+        if (tTri > 0.0f && tTri < hitMin) { hitMin = tTri; hit = true; }        // frag:562-565
+    }
+    for (int i = 0; i < F.sphereNum; i++) {                                     // frag:570-614
+        const RtSphere &s = F.sph[i];
+        const float dis = sphere_test(s, p.o, p.d);
+        if (dis > 0.0f && dis < hitMin) {
+            hitMin = dis;
+            hit = true;
+            const vec3 centre = rtm::mk(s.center[0], s.center[1], s.center[2]);
+            const vec3 n0 = rtm::sub(rtm::along(p.o, hitMin, p.d), centre);
+            const bool internal = rtm::dot(n0, p.d) > 0.0f;
+            const float temp = rand01(p.seed);
+            if (temp < s.specularRate) {
+                hitMin -= 0.00001f; material = 1; albedo = rtm::mk(s.albedo[0], s.albedo[1], s.albedo[2]);
+            } else if (temp < s.refractionRate) {
+                hitMin -= 0.00001f; material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f);
+            } else {
+                hitMin += 0.00001f; material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f);
+                refraction = internal ? 1.0f / 1.3f : 1.3f;
+            }
+            pos = rtm::along(p.o, hitMin, p.d);
+            nrm = rtm::sub(pos, centre);
+        }
+    }
+    if (!hit) return false;         // a miss can never reach a light afterwards (frag:655-672)
+    p.o = pos;
+    p.thr = rtm::mul(p.thr, albedo);                                            // frag:635
+    if (material == 0) {                                                        // frag:642-645
+        sample = rtm::scale(p.thr, 4.0f * 3.1415926f);                          // frag:673
+        return false;
+    }
+    if (material == 1) {                                                        // frag:637-641
+        float u, v;
+        sobol_pair(loopNum, (uint32_t)bounce, u, v);
+        cranley_patterson(uvx, uvy, F.width, F.height, u, v);
+        // SampleCosineHemisphere, frag:504-515; PI of frag:4 is 3.14159274f in fp32
+        const float r = __builtin_sqrtf(u);
+        const float theta = (v * 2.0f) * 3.14159274101257324f;
+        float sn, cs;
+        rtm::sincos_2pi_range(theta, sn, cs);
+        const float x = r * cs, y = r * sn;
+        const float z = __builtin_sqrtf(rtm::madd(-y, y, rtm::madd(-x, x, 1.0f)));
+        // toNormalHemisphere, frag:494-500
+        const vec3 helper = (fabsf(nrm.x) > 0.999f) ? rtm::mk(0.0f, 0.0f, 1.0f) : rtm::mk(1.0f, 0.0f, 0.0f);
+        const vec3 tangent = rtm::normalize(rtm::cross(nrm, helper));
+        const vec3 bitangent = rtm::normalize(rtm::cross(nrm, tangent));
+        const vec3 L = rtm::mk(rtm::madd(z, nrm.x, rtm::madd(y, bitangent.x, x * tangent.x)),
+                               rtm::madd(z, nrm.y, rtm::madd(y, bitangent.y, x * tangent.y)),
+                               rtm::madd(z, nrm.z, rtm::madd(y, bitangent.z, x * tangent.z)));
+        p.d = rtm::normalize(L);
+        p.thr = rtm::scale(p.thr, 0.5f);
+    } else if (material == 2) {                                                 // frag:542-545
+        const float k = 2.0f * rtm::dot(nrm, p.d);
+        p.d = rtm::mk(rtm::madd(-k, nrm.x, p.d.x), rtm::madd(-k, nrm.y, p.d.y), rtm::madd(-k, nrm.z, p.d.z));
+    } else {                                                                    // frag:548-556
+        const vec3 n2 = rtm::scale(nrm, -rtm::dot(p.d, nrm));
+        vec3 t = rtm::add(p.d, n2);
+        t = rtm::mk(t.x / refraction, t.y / refraction, t.z / refraction);
+        p.d = rtm::normalize(rtm::sub(t, n2));
+    }
+    const int next = bounce + 1;
+    if (next >= F.maxBounces) return false;                                     // loop bound, frag:624
+    if (next > 1) {                                                             // frag:625-630
+        if (rand01(p.seed) > 0.8f) return false;
+    }
+    return true;
+}
+
+// frag:677-689: seed and camera ray of pixel (px,py)
+__device__ __forceinline__ void generate_path(const FrameD &F, float randOrigin, uint32_t px, uint32_t py,
+                                              Path &p, float &uvx, float &uvy) {
+    uvx = ((float)px + 0.5f) / (float)F.width;
+    uvy = ((float)py + 0.5f) / (float)F.height;
+    p.seed = (uint32_t)((randOrigin * 6.95857f) * (uvx * uvy));
+    p.o = rtm::mk(F.cam.camPos[0], F.cam.camPos[1], F.cam.camPos[2]);
+    const float sx = (uvx * 2.0f) * F.cam.halfW;
+    const float sy = (uvy * 2.0f) * F.cam.halfH;
+    const vec3 dir = rtm::mk(rtm::madd(sy, F.cam.up[0], rtm::madd(sx, F.cam.right[0], F.cam.leftbottom[0])),
+                             rtm::madd(sy, F.cam.up[1], rtm::madd(sx, F.cam.right[1], F.cam.leftbottom[1])),
+                             rtm::madd(sy, F.cam.up[2], rtm::madd(sx, F.cam.right[2], F.cam.leftbottom[2])));
+    p.d = rtm::normalize(dir);
+    p.thr = rtm::mk(1.0f, 1.0f, 1.0f);
+}
+
+// Pixel of lane `lane` in 8x8 tile `tile` (tiles numbered row-major over the image).
+__device__ __forceinline__ bool tile_pixel(int tile, int lane, int width, int height, uint32_t &px, uint32_t &py) {
+    const int tilesX = (width + 7) >> 3;
+    const int ty = tile / tilesX, tx = tile - ty * tilesX;
+    px = (uint32_t)(tx * 8 + (lane & 7));
+    py = (uint32_t)(ty * 8 + (lane >> 3));
+    return px < (uint32_t)width && py < (uint32_t)height;
+}
+
+__device__ __forceinline__ void flush_counters(WorkCounters *wc, uint32_t rays, uint32_t nNode, uint32_t nTri, uint32_t nHit) {
+    // wave-level reduction, then one atomic per wave and counter
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off);
+        nNode += __shfl_down(nNode, off);
+        nTri += __shfl_down(nTri, off);
+        nHit += __shfl_down(nHit, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (rays) atomicAdd(&wc->rays, (unsigned long long)rays);
+        if (nNode) atomicAdd(&wc->node_tests, (unsigned long long)nNode);
+        if (nTri) atomicAdd(&wc->tri_tests, (unsigned long long)nTri);
+        if (nHit) atomicAdd(&wc->tri_hits, (unsigned long long)nHit);
+    }
+}
+
+// ------------------------------------------------------------------ megakernel
+
+// One thread per pixel, `count` frames per launch; accumulators stay in registers.
+template <bool CULL, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const FrameD F, const int firstLoopNum,
+                                                      const int count, const float *__restrict__ randOrigin,
+                                                      float *__restrict__ sum, float *__restrict__ mean,
+                                                      WorkCounters *__restrict__ wc) {
+    extern __shared__ uint32_t lds_stack[];
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    uint32_t px, py;
+    const bool valid = tile_pixel(tile, lane, F.width, F.height, px, py);
+    uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
+    if (valid) {
+        const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
+        float s0 = sum[o3], s1 = sum[o3 + 1], s2 = sum[o3 + 2];
+        float m0 = mean[o3], m1 = mean[o3 + 1], m2 = mean[o3 + 2];
+        for (int f = 0; f < count; f++) {
+            const uint32_t loopNum = (uint32_t)(firstLoopNum + f);
+            Path p; float uvx, uvy;
+            generate_path(F, randOrigin[f], px, py, p, uvx, uvy);
+            vec3 sample = rtm::mk(0.0f, 0.0f, 0.0f);
+            for (int b = 0; b < F.maxBounces; b++) {
+                float t; uint32_t tri;
+                closest_triangle<CULL, COUNT>(S, p.o, p.d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
+                cRays++;
+                if (COUNT && tri != REF_NONE) cHit++;
+                if (!shade_hit(F, S, p, t, tri, b, loopNum, uvx, uvy, sample)) break;
+            }
+            // frag:697 with an fp32 history, and the plain sum
+            const float n = (float)(int)loopNum;
+            const float wa = 1.0f / n, wb = (float)((int)loopNum - 1) / n;
+            m0 = rtm::madd(wa, sample.x, wb * m0);
+            m1 = rtm::madd(wa, sample.y, wb * m1);
+            m2 = rtm::madd(wa, sample.z, wb * m2);
+            s0 += sample.x; s1 += sample.y; s2 += sample.z;
+        }
+        sum[o3] = s0; sum[o3 + 1] = s1; sum[o3 + 2] = s2;
+        mean[o3] = m0; mean[o3 + 1] = m1; mean[o3 + 2] = m2;
+    }
+    flush_counters(wc, cRays, cNode, cTri, cHit);
+}
+
+// ------------------------------------------------------------------ wavefront pipeline
+
+// Reserves consecutive queue slots for the lanes of this wave that pass `want`.
+__device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (mask != 0ull) {
+        const int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+    }
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void store_path(const PathSoA &Q, uint32_t slot, const Path &p, uint32_t pix) {
+    Q.ox[slot] = p.o.x; Q.oy[slot] = p.o.y; Q.oz[slot] = p.o.z;
+    Q.dx[slot] = p.d.x; Q.dy[slot] = p.d.y; Q.dz[slot] = p.d.z;
+    Q.tr[slot] = p.thr.x; Q.tg[slot] = p.thr.y; Q.tb[slot] = p.thr.z;
+    Q.seed[slot] = p.seed; Q.pix[slot] = pix;
+}
+
+// generate: one wave per 8x8 pixel tile; writes the camera rays of one frame into queue 0
+// (slot = position in tile order, so a wave of the extend stage starts on a coherent tile)
+// and clears the frame's sample image.
+__global__ __launch_bounds__(BLOCK) void k_generate(const FrameD F, const float randOrigin, const PathSoA Q,
+                                                    uint32_t *__restrict__ qcount, float *__restrict__ cur) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    uint32_t px, py;
+    const bool valid = tile_pixel(tile, lane, F.width, F.height, px, py);
+    Path p; float uvx, uvy;
+    if (valid) {
+        generate_path(F, randOrigin, px, py, p, uvx, uvy);
+        const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
+        cur[o3] = 0.0f; cur[o3 + 1] = 0.0f; cur[o3 + 2] = 0.0f;
+    }
+    const uint32_t slot = wave_push(qcount, valid);
+    if (valid) store_path(Q, slot, p, (py << 16) | px);
+}
+
+// extend: persistent waves pull batches of 64 rays from the queue until it is empty.
+template <bool CULL, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA Q, const uint32_t *__restrict__ qcount,
+                                                  uint32_t *__restrict__ qhead, float *__restrict__ hitT,
+                                                  uint32_t *__restrict__ hitTri, WorkCounters *__restrict__ wc) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = *qcount;
+    uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
+    while (true) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(qhead, 64u);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const uint32_t slot = base + lane;
+        if (slot < n) {
+            const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
+            const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
+            float t; uint32_t tri;
+            closest_triangle<CULL, COUNT>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
+            hitT[slot] = t;
+            hitTri[slot] = tri;
+            cRays++;
+            if (COUNT && tri != REF_NONE) cHit++;
+        }
+    }
+    flush_counters(wc, cRays, cNode, cTri, cHit);
+}
+
+// shade: one thread per ray of the current queue; finished paths write their sample,
+// continuing paths are compacted into the next queue.
+__global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F, const int bounce, const uint32_t loopNum,
+                                                 const PathSoA Qin, const uint32_t *__restrict__ qcountIn,
+                                                 const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri,
+                                                 const PathSoA Qout, uint32_t *__restrict__ qcountOut,
+                                                 float *__restrict__ cur) {
+    const uint32_t n = *qcountIn;
+    const uint32_t stride = gridDim.x * BLOCK;
+    // every wave runs the same number of iterations so that wave_push sees whole waves
+    const uint32_t iters = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t slot = it * stride + blockIdx.x * BLOCK + threadIdx.x;
+        bool goOn = false;
+        Path p; uint32_t pix = 0;
+        if (slot < n) {
+            p.o = rtm::mk(Qin.ox[slot], Qin.oy[slot], Qin.oz[slot]);
+            p.d = rtm::mk(Qin.dx[slot], Qin.dy[slot], Qin.dz[slot]);
+            p.thr = rtm::mk(Qin.tr[slot], Qin.tg[slot], Qin.tb[slot]);
+            p.seed = Qin.seed[slot];
+            pix = Qin.pix[slot];
+            const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
+            const float uvx = ((float)px + 0.5f) / (float)F.width;
+            const float uvy = ((float)py + 0.5f) / (float)F.height;
+            vec3 sample;
+            goOn = shade_hit(F, S, p, hitT[slot], hitTri[slot], bounce, loopNum, uvx, uvy, sample);
+            if (!goOn && (sample.x != 0.0f || sample.y != 0.0f || sample.z != 0.0f)) {
+                const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
+                cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
+            }
+        }
+        const uint32_t outSlot = wave_push(qcountOut, goOn);
+        if (goOn) store_path(Qout, outSlot, p, pix);
+    }
+}
+
+// accumulate: frag:697 (fp32 history) and the plain sum.
+__global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ cur, float *__restrict__ sum,
+                                                      float *__restrict__ mean, const size_t nfloats, const int loopNum) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nfloats) return;
+    const float n = (float)loopNum;
+    const float wa = 1.0f / n, wb = (float)(loopNum - 1) / n;
+    const float c = cur[i];
+    mean[i] = rtm::madd(wa, c, wb * mean[i]);
+    sum[i] += c;
+}
+
+// Closest triangle for caller-supplied rays (rt_trace_rays).
+template <bool CULL>
+__global__ __launch_bounds__(BLOCK) void k_trace_rays(const SceneD S, const float *__restrict__ org, const float *__restrict__ dir,
+                                                      const long long n, float *__restrict__ tOut, int *__restrict__ idOut) {
+    extern __shared__ uint32_t lds_stack[];
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const vec3 o = rtm::mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+    const vec3 d = rtm::mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    float t; uint32_t tri, a = 0, b = 0;
+    closest_triangle<CULL, false>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, a, b);
+    tOut[i] = (tri == REF_NONE) ? -1.0f : t;
+    idOut[i] = (tri == REF_NONE) ? -1 : (int)tri;
+}
+
+// Device arithmetic exposed for the primitive-parity test: out[0..4] per element =
+// a/b, sqrt(|a|), fma(a,b,a), sin and cos of 2*pi*frac-range argument |a| mod 6.2831855.
+__global__ void k_selftest(const float *__restrict__ a, const float *__restrict__ b, const long long n, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    out[5 * i + 0] = x / y;
+    out[5 * i + 1] = __builtin_sqrtf(fabsf(x));
+    out[5 * i + 2] = rtm::madd(x, y, x);
+    float th = fabsf(y);
+    th = th - 6.2831855f * floorf(th / 6.2831855f);
+    float s, c;
+    rtm::sincos_2pi_range(th, s, c);
+    out[5 * i + 3] = s;
+    out[5 * i + 4] = c;
+}
+
+}  // namespace
+
+// ====================================================================== host side
+
+struct RtContext {
+    int device = 0;
+    int width = 0, height = 0;
+    hipStream_t stream = nullptr;
+    RtOptions opt{};
+    std::string err;
+
+    // scene
+    float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
+    int64_t nTris = 0, nInterior = 0;
+    SceneD scene{};
+    bool haveScene = false;
+
+    FrameD frame{};
+    bool haveCamera = false;
+    uint32_t sobol[RT_SOBOL_WORDS];
+    bool sobolDirty = true;
+
+    // images
+    float *dSum = nullptr, *dSumOwned = nullptr, *dMean = nullptr, *dCur = nullptr;
+    // wavefront state
+    float *dPathMem = nullptr;      // 2 x 11 arrays of P words
+    PathSoA q[2]{};
+    float *dHitT = nullptr; uint32_t *dHitTri = nullptr;
+    uint32_t *dQueueCtl = nullptr;  // per frame slot: counts[RT_MAX_BOUNCES+1], heads[RT_MAX_BOUNCES]
+    float *dRandOrigin = nullptr; int randCap = 0;
+    WorkCounters *dCounters = nullptr;
+    uint64_t frames = 0;
+    int numCU = 256;
+
+    // timing of the dominant kernel
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pendingEvents;
+    std::vector<hipEvent_t> freeEvents;
+    double kernelMs = 0.0; int64_t kernelLaunches = 0;
+};
+
+namespace {
+
+int fail(RtContext *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    rt::set_global_error(msg);
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((ctx), RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr int QCTL_WORDS = 2 * RT_MAX_BOUNCES + 2;     // counts[0..B], heads[0..B-1], padding
+
+hipEvent_t take_event(RtContext *ctx) {
+    if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+int resolve_events(RtContext *ctx) {
+    for (auto &pr : ctx->pendingEvents) {
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->kernelMs += (double)ms; ctx->kernelLaunches++;
+        ctx->freeEvents.push_back(pr.first); ctx->freeEvents.push_back(pr.second);
+    }
+    ctx->pendingEvents.clear();
+    return RT_OK;
+}
+
+// Converts the reference's linear tree + triangle list into the device layout; validates the
+// tree shape first so that a malformed tree is rejected on the host instead of faulting on the
+// GPU.
+int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtLinearBVHNode *nodes, int64_t m,
+                       std::vector<float4> &hNodes, std::vector<float4> &hTris, std::vector<float4> &hMats, SceneD &S) {
+    if (n <= 0 || m != 2 * n - 1) return fail(ctx, RT_E_INVALID, "scene upload: need n >= 1 triangles and exactly 2n-1 nodes");
+    if (n > (int64_t)0x7FFFFFF0) return fail(ctx, RT_E_INVALID, "scene upload: too many triangles");
+    std::vector<uint32_t> interiorIdx((size_t)m, REF_NONE);
+    std::vector<int32_t> depth((size_t)m, 0);
+    std::vector<uint8_t> referenced((size_t)m, 0);
+    std::vector<uint8_t> triSeen((size_t)n, 0);
+    uint32_t nInterior = 0; int maxDepth = 0;
+    referenced[0] = 1;
+    for (int64_t k = 0; k < m; k++) {
+        const RtLinearBVHNode &nd = nodes[k];
+        if (!referenced[(size_t)k]) return fail(ctx, RT_E_INVALID, "scene upload: node " + std::to_string(k) + " is not reachable in pre-order");
+        if (nd.triangleNum == 1) {
+            if (nd.offsetOrRc < 0 || nd.offsetOrRc >= n || triSeen[(size_t)nd.offsetOrRc])
+                return fail(ctx, RT_E_INVALID, "scene upload: leaf " + std::to_string(k) + " has a bad or repeated triangle index");
+            triSeen[(size_t)nd.offsetOrRc] = 1;
+        } else {
+            const int64_t l = k + 1, r = nd.offsetOrRc;
+            if (nd.triangleNum < 2 || r <= l || r >= m || nd.axis < 0 || nd.axis > 2 || referenced[(size_t)l] || referenced[(size_t)r])
+                return fail(ctx, RT_E_INVALID, "scene upload: interior node " + std::to_string(k) + " is malformed");
+            referenced[(size_t)l] = referenced[(size_t)r] = 1;
+            depth[(size_t)l] = depth[(size_t)r] = depth[(size_t)k] + 1;
+            if (depth[(size_t)l] > maxDepth) maxDepth = depth[(size_t)l];
+            interiorIdx[(size_t)k] = nInterior++;
+        }
+    }
+    if ((int64_t)nInterior != n - 1) return fail(ctx, RT_E_INVALID, "scene upload: tree does not have n-1 interior nodes");
+    if (maxDepth > 60) return fail(ctx, RT_E_INVALID, "scene upload: tree deeper than 60 levels");
+    auto ref_of = [&](int64_t k) -> uint32_t {
+        return nodes[k].triangleNum == 1 ? (LEAF_BIT | (uint32_t)nodes[k].offsetOrRc) : interiorIdx[(size_t)k];
+    };
+    hNodes.assign((size_t)nInterior * 4, make_float4(0, 0, 0, 0));
+    for (int64_t k = 0; k < m; k++) {
+        const RtLinearBVHNode &nd = nodes[k];
+        if (nd.triangleNum == 1) continue;
+        const RtLinearBVHNode &L = nodes[k + 1], &R = nodes[nd.offsetOrRc];
+        float4 *o = &hNodes[(size_t)interiorIdx[(size_t)k] * 4];
+        o[0] = make_float4(L.minBound[0], L.minBound[1], L.minBound[2], L.maxBound[0]);
+        o[1] = make_float4(L.maxBound[1], L.maxBound[2], R.minBound[0], R.minBound[1]);
+        o[2] = make_float4(R.minBound[2], R.maxBound[0], R.maxBound[1], R.maxBound[2]);
+        uint32_t w[4] = {ref_of(k + 1), ref_of(nd.offsetOrRc), (uint32_t)nd.axis, 0u};
+        std::memcpy(&o[3], w, 16);
+    }
+    hTris.resize((size_t)n * 4); hMats.resize((size_t)n * 3);
+    for (int64_t i = 0; i < n; i++) {
+        const RtTriangle &t = tris[i];
+        const vec3 v0 = rtm::mk(t.v[0][0], t.v[0][1], t.v[0][2]);
+        const vec3 v1 = rtm::mk(t.v[1][0], t.v[1][1], t.v[1][2]);
+        const vec3 v2 = rtm::mk(t.v[2][0], t.v[2][1], t.v[2][2]);
+        const vec3 N = rtm::normalize(rtm::cross(rtm::sub(v1, v0), rtm::sub(v2, v0)));      // frag:257-259
+        const float D = -rtm::dot(N, v0);                                                  // frag:262
+        hTris[(size_t)i * 4 + 0] = make_float4(v0.x, v0.y, v0.z, v1.x);
+        hTris[(size_t)i * 4 + 1] = make_float4(v1.y, v1.z, v2.x, v2.y);
+        hTris[(size_t)i * 4 + 2] = make_float4(v2.z, N.x, N.y, N.z);
+        hTris[(size_t)i * 4 + 3] = make_float4(D, 0.0f, 0.0f, 0.0f);
+        hMats[(size_t)i * 3 + 0] = make_float4(t.ka[0], t.ka[1], t.ka[2], t.kd[0]);
+        hMats[(size_t)i * 3 + 1] = make_float4(t.kd[1], t.kd[2], t.ks[0], t.ks[1]);
+        hMats[(size_t)i * 3 + 2] = make_float4(t.ks[2], 0.0f, 0.0f, 0.0f);
+    }
+    S = SceneD{};
+    float maxAbs = 0.0f;
+    for (int c = 0; c < 3; c++) {
+        S.rootMin[c] = nodes[0].minBound[c]; S.rootMax[c] = nodes[0].maxBound[c];
+        maxAbs = std::fmax(maxAbs, std::fmax(std::fabs(S.rootMin[c]), std::fabs(S.rootMax[c])));
+    }
+    S.rootRef = (n == 1) ? (LEAF_BIT | 0u) : 0u;
+    if (n == 1 && nodes[0].offsetOrRc != 0) return fail(ctx, RT_E_INVALID, "scene upload: single leaf must reference triangle 0");
+    S.cullEps = maxAbs * (1.0f / 1024.0f);
+    S.stackEntries = maxDepth + 1;
+    return RT_OK;
+}
+
+int ensure_sobol(RtContext *ctx) {
+    // the table is per device (one module per device); upload before every batch whose
+    // context last touched it is not this one
+    static thread_local const RtContext *lastOwner = nullptr;
+    if (ctx->sobolDirty || lastOwner != ctx) {
+        HIP_TRY(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sobolV), ctx->sobol, sizeof ctx->sobol, 0, hipMemcpyHostToDevice, ctx->stream));
+        ctx->sobolDirty = false;
+        lastOwner = ctx;
+    }
+    return RT_OK;
+}
+
+size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
+
+}  // namespace
+
+extern "C" {
+
+int rt_default_options(RtOptions *out) {
+    if (!out) return fail(nullptr, RT_E_INVALID, "rt_default_options: null pointer");
+    out->max_bounces = 4;
+    out->pipeline = RT_PIPELINE_WAVEFRONT;
+    out->cull = 1;
+    out->count_work = 0;
+    return RT_OK;
+}
+
+int rt_create(RtContext **out, int width, int height, int device) {
+    if (!out) return fail(nullptr, RT_E_INVALID, "rt_create: null pointer");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384)
+        return fail(nullptr, RT_E_INVALID, "rt_create: width/height must be in 1..16384");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RT_E_HIP, "rt_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, RT_E_INVALID, "rt_create: device index out of range");
+    RtContext *ctx = new (std::nothrow) RtContext;
+    if (!ctx) return fail(nullptr, RT_E_NOMEM, "rt_create: out of memory");
+    ctx->device = device; ctx->width = width; ctx->height = height;
+    rt_default_options(&ctx->opt);
+    rt_sobol_default_table(ctx->sobol);
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) ctx->numCU = prop.multiProcessorCount;
+    const size_t P = (size_t)width * height;
+    const size_t img = P * 3 * sizeof(float);
+    if (e == hipSuccess) e = hipMalloc(&ctx->dSumOwned, img);
+    if (e == hipSuccess) e = hipMalloc(&ctx->dMean, img);
+    if (e == hipSuccess) e = hipMalloc(&ctx->dCur, img);
+    if (e == hipSuccess) e = hipMalloc(&ctx->dPathMem, 2 * 11 * P * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&ctx->dHitT, P * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&ctx->dHitTri, P * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->dQueueCtl, QCTL_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->dCounters, sizeof(WorkCounters));
+    if (e != hipSuccess) {
+        std::string msg = std::string("rt_create: ") + hipGetErrorString(e);
+        rt_destroy(ctx);
+        return fail(nullptr, RT_E_HIP, msg);
+    }
+    ctx->dSum = ctx->dSumOwned;
+    for (int b = 0; b < 2; b++) {
+        float *base = ctx->dPathMem + (size_t)b * 11 * P;
+        PathSoA &q = ctx->q[b];
+        q.ox = base; q.oy = base + P; q.oz = base + 2 * P;
+        q.dx = base + 3 * P; q.dy = base + 4 * P; q.dz = base + 5 * P;
+        q.tr = base + 6 * P; q.tg = base + 7 * P; q.tb = base + 8 * P;
+        q.seed = (uint32_t *)(base + 9 * P); q.pix = (uint32_t *)(base + 10 * P);
+    }
+    ctx->frame.width = width; ctx->frame.height = height;
+    ctx->frame.maxBounces = ctx->opt.max_bounces;
+    int rc = rt_reset(ctx);
+    if (rc != RT_OK) { std::string msg = ctx->err; rt_destroy(ctx); return fail(nullptr, rc, msg); }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(RtContext *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : ctx->freeEvents) hipEventDestroy(e);
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
+    hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
+    hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
+    hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
+    delete ctx;
+}
+
+int rt_set_stream(RtContext *ctx, void *hip_stream) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_set_stream: null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    return RT_OK;
+}
+
+int rt_set_options(RtContext *ctx, const RtOptions *opt) {
+    if (!ctx || !opt) return fail(ctx, RT_E_INVALID, "rt_set_options: null pointer");
+    if (opt->max_bounces < 1 || opt->max_bounces > RT_MAX_BOUNCES) return fail(ctx, RT_E_INVALID, "rt_set_options: max_bounces must be in 1..8");
+    if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
+    ctx->opt = *opt;
+    ctx->frame.maxBounces = opt->max_bounces;
+    return RT_OK;
+}
+
+int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtLinearBVHNode *nodes, int64_t m) {
+    if (!ctx || !tris || !nodes) return fail(ctx, RT_E_INVALID, "rt_scene_upload: null pointer");
+    std::vector<float4> hNodes, hTris, hMats; SceneD S;
+    int rc = build_device_scene(ctx, tris, n, nodes, m, hNodes, hTris, hMats, S);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
+    ctx->dNodes = ctx->dTris = ctx->dMats = nullptr; ctx->haveScene = false;
+    const size_t nodeBytes = std::max<size_t>(hNodes.size(), 4) * sizeof(float4);
+    HIP_TRY(ctx, hipMalloc(&ctx->dNodes, nodeBytes));
+    HIP_TRY(ctx, hipMalloc(&ctx->dTris, hTris.size() * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&ctx->dMats, hMats.size() * sizeof(float4)));
+    if (!hNodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->dNodes, hNodes.data(), hNodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dTris, hTris.data(), hTris.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dMats, hMats.data(), hMats.size() * sizeof(float4), hipMemcpyHostToDevice));
+    S.nodes = ctx->dNodes; S.tris = ctx->dTris; S.mats = ctx->dMats;
+    ctx->scene = S; ctx->nTris = n; ctx->nInterior = n - 1; ctx->haveScene = true;
+    return RT_OK;
+}
+
+int rt_scene_upload_textures(RtContext *ctx, const float *tex_triangle, int64_t n, const float *tex_bvh, int64_t m) {
+    if (!ctx || !tex_triangle || !tex_bvh) return fail(ctx, RT_E_INVALID, "rt_scene_upload_textures: null pointer");
+    if (n <= 0 || m <= 0) return fail(ctx, RT_E_INVALID, "rt_scene_upload_textures: empty scene");
+    std::vector<RtTriangle> tris((size_t)n); std::vector<RtLinearBVHNode> nodes((size_t)m);
+    for (int64_t i = 0; i < n; i++) {           // record layout of ObjectTexture.h:86-109
+        const float *r = tex_triangle + i * 33; RtTriangle &t = tris[(size_t)i];
+        std::memset(&t, 0, sizeof t);
+        for (int k = 0; k < 3; k++) {
+            for (int c = 0; c < 3; c++) { t.v[k][c] = r[k * 8 + c]; t.n[k][c] = r[k * 8 + 3 + c]; }
+            t.tex[k][0] = r[k * 8 + 6]; t.tex[k][1] = r[k * 8 + 7];
+        }
+        for (int c = 0; c < 3; c++) { t.ka[c] = r[24 + c]; t.kd[c] = r[27 + c]; t.ks[c] = r[30 + c]; }
+    }
+    for (int64_t i = 0; i < m; i++) {           // ObjectTexture.h:144-154; ints recovered as int(f + 0.5), frag:180-182
+        const float *r = tex_bvh + i * 9; RtLinearBVHNode &nd = nodes[(size_t)i];
+        for (int c = 0; c < 3; c++) { nd.maxBound[c] = r[c]; nd.minBound[c] = r[3 + c]; }
+        nd.triangleNum = (int32_t)(r[6] + 0.5f);
+        nd.offsetOrRc = (int32_t)(r[7] + 0.5f);
+        nd.axis = (nd.triangleNum == 1) ? -1 : (int32_t)(r[8] + 0.5f);
+    }
+    return rt_scene_upload(ctx, tris.data(), n, nodes.data(), m);
+}
+
+int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]) {
+    if (!ctx || !v) return fail(ctx, RT_E_INVALID, "rt_set_sobol: null pointer");
+    std::memcpy(ctx->sobol, v, sizeof ctx->sobol);
+    ctx->sobolDirty = true;
+    return RT_OK;
+}
+
+int rt_set_spheres(RtContext *ctx, const RtSphere *spheres, int count) {
+    if (!ctx || count < 0 || count > RT_MAX_SPHERES || (count > 0 && !spheres)) return fail(ctx, RT_E_INVALID, "rt_set_spheres: count must be in 0..10");
+    ctx->frame.sphereNum = count;
+    for (int i = 0; i < count; i++) ctx->frame.sph[i] = spheres[i];
+    return RT_OK;
+}
+
+int rt_set_camera(RtContext *ctx, const RtCamera *cam) {
+    if (!ctx || !cam) return fail(ctx, RT_E_INVALID, "rt_set_camera: null pointer");
+    ctx->frame.cam = *cam;
+    ctx->haveCamera = true;
+    return RT_OK;
+}
+
+int rt_reset(RtContext *ctx) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_reset: null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t img = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dSum, 0, img, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dMean, 0, img, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dCur, 0, img, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(WorkCounters), ctx->stream));
+    int rc = resolve_events(ctx);
+    ctx->kernelMs = 0.0; ctx->kernelLaunches = 0;
+    ctx->frames = 0;
+    return rc;
+}
+
+int rt_synchronize(RtContext *ctx) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_synchronize: null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *rand_origin) {
+    if (!ctx || !rand_origin) return fail(ctx, RT_E_INVALID, "rt_render_frames: null pointer");
+    if (count <= 0 || first_loopnum < 1 || (int64_t)first_loopnum + count > (int64_t)1 << 30) return fail(ctx, RT_E_INVALID, "rt_render_frames: need first_loopnum >= 1 and count >= 1");
+    if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_render_frames: no scene uploaded");
+    if (!ctx->haveCamera) return fail(ctx, RT_E_STATE, "rt_render_frames: no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_sobol(ctx);
+    if (rc != RT_OK) return rc;
+    if (ctx->pendingEvents.size() > 8192) { rc = resolve_events(ctx); if (rc != RT_OK) return rc; }
+    const FrameD &F = ctx->frame;
+    const SceneD &S = ctx->scene;
+    const int tiles = ((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
+    const int tileBlocks = (tiles + BLOCK / 64 - 1) / (BLOCK / 64);
+    const size_t lds = stack_bytes(ctx);
+    const bool cull = ctx->opt.cull != 0, cnt = ctx->opt.count_work != 0;
+    hipStream_t st = ctx->stream;
+
+    if (ctx->opt.pipeline == RT_PIPELINE_MEGAKERNEL) {
+        if (count > ctx->randCap) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            hipFree(ctx->dRandOrigin); ctx->dRandOrigin = nullptr; ctx->randCap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dRandOrigin, (size_t)count * sizeof(float)));
+            ctx->randCap = count;
+        }
+        // pageable host memory: the copy has returned from the caller's buffer when this call returns
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dRandOrigin, rand_origin, (size_t)count * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
+        if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
+        HIP_TRY(ctx, hipEventRecord(e0, st));
+#define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSum, ctx->dMean, ctx->dCounters)
+        if (cull) { if (cnt) LAUNCH_MEGA(true, true); else LAUNCH_MEGA(true, false); }
+        else { if (cnt) LAUNCH_MEGA(false, true); else LAUNCH_MEGA(false, false); }
+#undef LAUNCH_MEGA
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(e1, st));
+        ctx->pendingEvents.emplace_back(e0, e1);
+        ctx->frames += (uint64_t)count;
+        return RT_OK;
+    }
+
+    // wavefront pipeline, one frame at a time
+    const int extendBlocks = ctx->numCU * 4;        // persistent: 16 waves per CU
+    const int shadeBlocks = ctx->numCU * 8;
+    const size_t nfloats = (size_t)ctx->width * ctx->height * 3;
+    const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
+    uint32_t *counts = ctx->dQueueCtl, *heads = ctx->dQueueCtl + RT_MAX_BOUNCES + 1;
+    for (int f = 0; f < count; f++) {
+        const int loopNum = first_loopnum + f;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dQueueCtl, 0, QCTL_WORDS * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_generate, dim3(tileBlocks), dim3(BLOCK), 0, st, F, rand_origin[f], ctx->q[0], counts + 0, ctx->dCur);
+        for (int b = 0; b < F.maxBounces; b++) {
+            const PathSoA &qin = ctx->q[b & 1], &qout = ctx->q[(b + 1) & 1];
+            hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
+            if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
+            HIP_TRY(ctx, hipEventRecord(e0, st));
+#define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, counts + b, heads + b, ctx->dHitT, ctx->dHitTri, ctx->dCounters)
+            if (cull) { if (cnt) LAUNCH_EXT(true, true); else LAUNCH_EXT(true, false); }
+            else { if (cnt) LAUNCH_EXT(false, true); else LAUNCH_EXT(false, false); }
+#undef LAUNCH_EXT
+            HIP_TRY(ctx, hipEventRecord(e1, st));
+            ctx->pendingEvents.emplace_back(e0, e1);
+            hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, qin, counts + b,
+                               ctx->dHitT, ctx->dHitTri, qout, counts + b + 1, ctx->dCur);
+        }
+        hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->frames += (uint64_t)count;
+    return RT_OK;
+}
+
+int rt_read_mean(RtContext *ctx, float *rgb) {
+    if (!ctx || !rgb) return fail(ctx, RT_E_INVALID, "rt_read_mean: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dMean, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_read_sum(RtContext *ctx, float *rgb) {
+    if (!ctx || !rgb) return fail(ctx, RT_E_INVALID, "rt_read_sum: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dSum, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_sum_device_ptr(RtContext *ctx, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return fail(ctx, RT_E_INVALID, "rt_sum_device_ptr: null pointer");
+    *dev_ptr = ctx->dSum;
+    return RT_OK;
+}
+
+int rt_bind_sum_buffer(RtContext *ctx, float *dev_ptr) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_bind_sum_buffer: null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dSum = dev_ptr ? dev_ptr : ctx->dSumOwned;
+    return RT_OK;
+}
+
+int rt_get_stats(RtContext *ctx, RtStats *out) {
+    if (!ctx || !out) return fail(ctx, RT_E_INVALID, "rt_get_stats: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    WorkCounters wc;
+    HIP_TRY(ctx, hipMemcpyAsync(&wc, ctx->dCounters, sizeof wc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays = wc.rays; out->node_tests = wc.node_tests; out->tri_tests = wc.tri_tests; out->tri_hits = wc.tri_hits;
+    out->frames = ctx->frames;
+    return RT_OK;
+}
+
+int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches) {
+    if (!ctx || !total_ms || !launches) return fail(ctx, RT_E_INVALID, "rt_get_kernel_time: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = resolve_events(ctx);
+    *total_ms = ctx->kernelMs; *launches = ctx->kernelLaunches;
+    return rc;
+}
+
+int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64_t n, float *t_out, int32_t *id_out) {
+    if (!ctx || !origins || !dirs || !t_out || !id_out || n < 0) return fail(ctx, RT_E_INVALID, "rt_trace_rays: bad argument");
+    if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_trace_rays: no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (n > (int64_t)1 << 28) return fail(ctx, RT_E_INVALID, "rt_trace_rays: more than 2^28 rays per call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dO = nullptr, *dD = nullptr, *dT = nullptr; int *dI = nullptr;
+    hipError_t e = hipMalloc(&dO, (size_t)n * 12);
+    if (e == hipSuccess) e = hipMalloc(&dD, (size_t)n * 12);
+    if (e == hipSuccess) e = hipMalloc(&dT, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dI, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dD, dirs, (size_t)n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int blocks = (int)((n + BLOCK - 1) / BLOCK);
+        if (ctx->opt.cull) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(BLOCK), stack_bytes(ctx), ctx->stream, ctx->scene, dO, dD, (long long)n, dT, dI);
+        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(blocks), dim3(BLOCK), stack_bytes(ctx), ctx->stream, ctx->scene, dO, dD, (long long)n, dT, dI);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(t_out, dT, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(id_out, dI, (size_t)n * 4, hipMemcpyDeviceToHost);
+    hipFree(dO); hipFree(dD); hipFree(dT); hipFree(dI);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+// Not part of the reference boundary: runs the device's divide / sqrt / fma / sincos on
+// caller data so that a test can compare them with the host's (out has 5*n floats).
+int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out) {
+    if (!ctx || !a || !b || !out || n <= 0 || n > (int64_t)1 << 26) return fail(ctx, RT_E_INVALID, "rt_selftest_arith: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dA = nullptr, *dB = nullptr, *dOut = nullptr;
+    hipError_t e = hipMalloc(&dA, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dB, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dOut, (size_t)n * 20);
+    if (e == hipSuccess) e = hipMemcpy(dA, a, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dB, b, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dA, dB, (long long)n, dOut);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)n * 20, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dB); hipFree(dOut);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, std::string("rt_selftest_arith: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+const char *rt_last_error(const RtContext *ctx) { return ctx ? ctx->err.c_str() : rt::global_error(); }
+
+}  // extern "C"

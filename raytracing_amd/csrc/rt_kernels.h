@@ -1,0 +1,69 @@
+// Device-side data layout and kernels of the tracer (gfx950, wave64).
+//
+// What the reference does per pixel in one GLSL fragment shader
+// (RayTracerFragmentShader.glsl, "frag") is split here into the stages of a wavefront path
+// tracer that share the device functions below:
+//   generate    frag:677-689   seed + camera ray
+//   extend      frag:373-456   closest triangle over the BVH (hitBVH without the material draw)
+//   shade       frag:457-488, 558-675   material draw, spheres, scatter, Russian roulette
+//   accumulate  frag:683,697-698        running mean (+ a plain sum for multi-GPU reduction)
+// A megakernel that runs the same functions in one thread per pixel is kept beside it.
+//
+// HBM layout (built once by rt_scene_upload from the reference's arrays):
+//   nodes: one 64-byte record per INTERIOR node of the reference tree holding the boxes of
+//          both children, so one fetch decides both (the reference fetches 9 floats per child
+//          and tests a box only after descending to it).  Leaves (always one triangle,
+//          BVH.h:207-211) have no record: the parent stores LEAF|triangle index.
+//   tris:  one 64-byte record per triangle: v0 v1 v2, the unit normal N and plane offset D
+//          that hitTriangle (frag:257-262) recomputes for every ray (they depend on the
+//          triangle only, and are computed with the same arithmetic).
+//   mats:  one 48-byte record per triangle: ka kd ks (frag:220-230), read once per hit.
+// The reference's 33-float triangle texel and 9-float node texel carry 15 resp. 0 floats the
+// shader never uses (normals, uvs: frag:196-218).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+#include "rt_math.h"
+
+namespace rtd {
+
+using rtm::vec3;
+
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;     // also "no triangle"
+
+struct SceneD {
+    const float4 *nodes;    // 4 x float4 per interior node
+    const float4 *tris;     // 4 x float4 per triangle
+    const float4 *mats;     // 3 x float4 per triangle
+    float rootMin[3];
+    float rootMax[3];
+    uint32_t rootRef;       // LEAF_BIT|0 for a one-triangle scene, 0 otherwise, REF_NONE if empty
+    float cullEps;          // 2^-10 * largest |coordinate| of the root box
+    int32_t stackEntries;   // LDS stack slots per lane (tree height)
+};
+
+struct FrameD {
+    RtCamera cam;
+    int32_t width, height;
+    int32_t maxBounces;
+    int32_t sphereNum;
+    RtSphere sph[RT_MAX_SPHERES];
+};
+
+// Path state of the wavefront pipeline, structure of arrays over queue slots.
+struct PathSoA {
+    float *ox, *oy, *oz;
+    float *dx, *dy, *dz;
+    float *tr, *tg, *tb;    // throughput ("color" of frag:622)
+    uint32_t *seed;         // wseed, frag:35
+    uint32_t *pix;          // py << 16 | px
+};
+
+struct WorkCounters {       // device-side twin of RtStats
+    unsigned long long rays, node_tests, tri_tests, tri_hits;
+};
+
+}  // namespace rtd
