@@ -234,7 +234,7 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
 /* Diagnostics with no counterpart in the reference, used by the parity tests.
  * rt_selftest_nth_element: the builder's selection routine alone (keys with ids carried
  * along), to compare its permutation with std::nth_element's (BVH.h:222).
- * rt_selftest_arith: the device's a/b, sqrt|a|, fma(a,b,a), and sin/cos of |b| mod 2*pi, five
+ * rt_selftest_arith: the device's a/b, sqrt|a|, fma(a,b,a), and sin/cos of |b| (0 outside [0, 2*pi]), five
  * floats per element, to compare with the host's arithmetic. */
 int rt_selftest_nth_element(float *keys, int32_t *ids, int64_t n, int64_t nth);
 int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out);

@@ -96,9 +96,9 @@ typedef struct {
 typedef struct {
     uint64_t rays;          /* closest-hit queries excluding re-traces of a ray that already missed */
     uint64_t raysRef;       /* hitWorld() calls exactly as the reference makes them (frag:631) */
-    uint64_t nodeTests;     /* IntersectBound() calls (frag:389) */
-    uint64_t triTests;      /* hitTriangle() calls (frag:395) */
-    uint64_t triHits;       /* hitBVH() returning true (frag:457) */
+    uint64_t nodeTests;     /* IntersectBound() calls (frag:389), re-traces excluded */
+    uint64_t triTests;      /* hitTriangle() calls (frag:395), re-traces excluded */
+    uint64_t triHits;       /* hitBVH() returning true (frag:457), re-traces excluded */
 } OrStats;
 
 /* ------------------------------------------------------------ vector math */
@@ -170,6 +170,7 @@ typedef struct {
     HitRecord rec;          /* frag:251 (global) */
     OrStats *st;
     int hitTriIndex;        /* instrumentation: index of the triangle hitBVH kept */
+    int retrace;            /* instrumentation: this hitWorld call repeats a ray that already missed */
 } Px;
 
 /* frag:36-47 */
@@ -331,13 +332,13 @@ static int hit_bvh(Px *p, Ray ray) {
     if (sc->bvhNum <= 0) return 0;   /* the reference would read an empty texture; no geometry = no hit */
     while (1) {
         Node node = get_node(sc, currentNodeIndex);
-        if (p->st) p->st->nodeTests++;
+        if (p->st && !p->retrace) p->st->nodeTests++;
         if (intersect_bound(node.minB, node.maxB, &ray, invDir, neg)) {
             if (node.triangleNum == 1) {
                 for (int i = 0; i < node.triangleNum; ++i) {
                     int offset = node.offsetOrRc + i;
                     Tri tri_t = get_triangle(sc, offset);
-                    if (p->st) p->st->triTests++;
+                    if (p->st && !p->retrace) p->st->triTests++;
                     float dis_t = hit_triangle(&tri_t, &ray);
                     if (dis_t > 0.0f && dis_t < ray.hitMin) {
                         ray.hitMin = dis_t;
@@ -364,7 +365,7 @@ static int hit_bvh(Px *p, Ray ray) {
         }
     }
     if (hit) {
-        if (p->st) p->st->triHits++;
+        if (p->st && !p->retrace) p->st->triHits++;
         HitRecord *rec = &p->rec;
         rec->Pos = along(ray.origin, ray.hitMin, ray.direction);
         rec->Normal = triangle_normal(&tri, &ray);
@@ -507,6 +508,7 @@ static v3 shading(Px *p, Ray r) {
             }
         }
         if (p->st) { p->st->raysRef++; if (!missed) p->st->rays++; }
+        p->retrace = missed;
         if (hit_world(p, r)) {
             const HitRecord *rec = &p->rec;
             r.origin = rec->Pos;

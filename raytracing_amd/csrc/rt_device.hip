@@ -520,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_rays(const SceneD S, const floa
 }
 
 // Device arithmetic exposed for the primitive-parity test: out[0..4] per element =
-// a/b, sqrt(|a|), fma(a,b,a), sin and cos of 2*pi*frac-range argument |a| mod 6.2831855.
+// a/b, sqrt(|a|), fma(a,b,a), sin and cos of |b| (taken as 0 outside [0, 2*pi]).
 __global__ void k_selftest(const float *__restrict__ a, const float *__restrict__ b, const long long n, float *__restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -529,7 +529,7 @@ __global__ void k_selftest(const float *__restrict__ a, const float *__restrict_
     out[5 * i + 1] = __builtin_sqrtf(fabsf(x));
     out[5 * i + 2] = rtm::madd(x, y, x);
     float th = fabsf(y);
-    th = th - 6.2831855f * floorf(th / 6.2831855f);
+    if (!(th <= 6.2831855f)) th = 0.0f;     // the sampler's argument never leaves [0, 2*pi]
     float s, c;
     rtm::sincos_2pi_range(th, s, c);
     out[5 * i + 3] = s;

@@ -38,15 +38,17 @@ def test_device_arithmetic_matches_host():
     # double rounding can differ from a true fma in rare cases; allow 1 ulp on those
     same = out[:, 2] == fma
     assert same.mean() > 0.999
-    lib = ol.load()
+    # sin/cos on the range the sampler uses, [0, 2*pi], against the oracle's fixed sequence
     import ctypes as C
-    th = np.abs(b)
-    th = (th - np.float32(6.2831855) * np.floor(th / np.float32(6.2831855))).astype(np.float32)
+    lib = ol.load()
+    m = 1 << 16
+    th = np.concatenate([rng.uniform(0.0, 6.2831855, size=m - 5), [0.0, 1.5707964, 3.1415927, 4.712389, 6.2831855]]).astype(np.float32)
+    out = r.selftest_arith(np.ones(m, dtype=np.float32), th)
     s, c = C.c_float(), C.c_float()
-    idx = rng.integers(0, n, size=20000)
-    for i in idx:
+    for i in range(m):
         lib.or_sincos(C.c_float(float(th[i])), C.byref(s), C.byref(c))
         assert out[i, 3] == np.float32(s.value) and out[i, 4] == np.float32(c.value), (i, th[i])
+        assert abs(float(out[i, 3]) - np.sin(float(th[i]))) < 3e-7 and abs(float(out[i, 4]) - np.cos(float(th[i]))) < 3e-7
 
 
 @pytest.mark.parametrize("cull", [False, True])
