@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch: `--spp-per-step` frames (samples per pixel)
+of the workload at its full resolution.  For N > 1 the driver launches one process per GPU with
+torch.distributed.run; every rank renders its own block of frame indices (weak scaling), and
+the per-rank fp32 sums are reduced to rank 0 by one RCCL reduce inside the timed region.
+
+Prints ONE JSON line on rank 0.  `value` is Mrays/s over all ranks: rays actually traced
+(camera ray + one per scatter; rays that already missed are not re-traced) divided by the
+max-over-ranks wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (BASELINE.json configs index, description, width, height, bounces, scene builder args)
+    "dragon1m": (2, "procedural 1.31M-triangle displaced icosphere in the reference room, 1080p, 4 bounces",
+                 1920, 1080, 4, dict(kind=0, level=8, copies=1)),
+    "demo": (1, "reference demo scene (32 triangles, 2 spheres), 1080p, 4 bounces",
+             1920, 1080, 4, None),
+    "sponza": (3, "room x3 with 32 tessellated columns (262k triangles, diffuse/mirror/glass), 4K, 4 bounces",
+               3840, 2160, 4, dict(kind=1, level=64, copies=1)),
+    "stress10m": (4, "8 displaced icospheres (10.5M triangles) in the reference room, 1080p, 8 bounces",
+                  1920, 1080, 8, dict(kind=0, level=8, copies=8)),
+}
+SEED = 20221003
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak
+
+
+def build_scene(rt, spec):
+    sc = rt.Scene()
+    if spec is None:
+        sc.push_demo()
+    else:
+        sc.push_synthetic(spec["kind"], spec["level"], spec["copies"], 12345)
+    t0 = time.time()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    return sc, tris, nodes, time.time() - t0
+
+
+def cpu_baseline(rt, tris, nodes, spheres, cam, W, H, bounces, ro, budget_s=15.0):
+    """The CPU oracle (a port of the reference shader, OpenMP over rows) timed on a band of rows
+    of frame 1 of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    threads = min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    osc = ol.scene_from_build(tris, nodes, W, H, rt.sobol_default_table(), spheres, max_bounces=bounces)
+    # whole frames 1, 2, ... until about budget_s of CPU time has been spent (at least one frame)
+    rays, frames, t0 = 0, 0, time.time()
+    while frames < len(ro) and (frames == 0 or time.time() - t0 < budget_s):
+        _, _, st = osc.render_frame(cam, frames + 1, float(ro[frames]), want_stats=True)
+        rays += st["rays"]
+        frames += 1
+    dt = time.time() - t0
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"frames 1..{frames} of the same workload at full resolution ({rays} rays, {dt:.1f} s), "
+                      "oracle/rt_oracle.c with OpenMP over rows; no hitMin culling, re-traces excluded from the count"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="dragon1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cull", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    import raytracing_amd as rt
+    from raytracing_amd import partition
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg_idx, desc, W, H, bounces, spec = WORKLOADS[args.workload]
+    sc, tris, nodes, bvh_s = build_scene(rt, spec)
+    cam = rt.camera_default(W, H)
+    pipeline = rt.PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else rt.PIPELINE_MEGAKERNEL
+
+    r = rt.Renderer(W, H, local_rank)
+    r.upload(tris, nodes)
+    r.set_spheres(sc.spheres())
+    r.set_camera(cam)
+    r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False)
+    sum_t = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
+    r.bind_sum_buffer(sum_t.data_ptr())
+
+    F, K, Wm = args.spp_per_step, args.steps, args.warmup
+    total_frames = (K + Wm) * world * F
+    ro = partition.rand_origin_stream(SEED, total_frames)
+
+    def run_step(step):
+        first, cnt = partition.frame_block(rank, world, step, F)
+        r.render(first, ro[first - 1:first - 1 + cnt])
+
+    for s in range(Wm):
+        run_step(s)
+    r.synchronize()
+    # warmup frames are not part of the measured image or counters
+    r.reset()
+    sum_t.zero_()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        run_step(Wm + s)
+    if dist:
+        partition.reduce_sum_to_root(sum_t, dist)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    stats = r.stats()
+    kernel_ms, launches = r.kernel_time()
+    rays_local = stats["rays"]
+    if dist:
+        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays_total = float(t[1])
+    else:
+        rays_total = float(rays_local)
+
+    result = None
+    if rank == 0:
+        mean_img = (sum_t / float(K * world * F)).cpu().numpy()
+        value = rays_total / elapsed / 1e6
+        # instrumented re-run of this rank's timed frames: identical traversal, counts the work
+        r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=True)
+        r.reset()
+        ksteps = min(K, 2)
+        for s in range(ksteps):
+            run_step(Wm + s)
+        r.synchronize()
+        w = r.stats()
+        bytes_alg = 32.0 * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]
+        bytes_per_ray = bytes_alg / max(w["rays"], 1)
+        achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        dominant = "k_extend" if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
+        result = {
+            "metric": "Mrays/sec (paths x bounces) at 1080p" if H == 1080 else "Mrays/sec (paths x bounces)",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc} (BASELINE.json configs[{cfg_idx}])",
+                       "triangles": int(tris.shape[0]), "bvh_nodes": int(nodes.shape[0]),
+                       "resolution": f"{W}x{H}", "spp_per_step": F, "max_bounces": bounces,
+                       "pipeline": args.pipeline, "cull": not args.no_cull,
+                       "parallelism": f"spp-partition x{world}, one RCCL sum-reduce" if world > 1 else "single GPU",
+                       "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
+                       "image_mean": float(mean_img.mean())},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_ray": round(bytes_per_ray, 1),
+                         "nodes_per_ray": round(w["node_tests"] / max(w["rays"], 1), 2),
+                         "tris_per_ray": round(w["tri_tests"] / max(w["rays"], 1), 2),
+                         "kernel_ms_per_launch": round(kernel_ms / max(launches, 1), 4), "launches": launches,
+                         "kernel_share_of_wall": round(kernel_ms * 1e-3 / elapsed, 3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(rt, tris, nodes, sc.spheres(), cam, W, H, bounces, ro)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    r.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

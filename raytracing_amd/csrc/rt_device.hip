@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,6 +23,12 @@ __constant__ uint32_t c_sobolV[RT_SOBOL_WORDS];
 namespace {
 
 constexpr int BLOCK = 256;          // 4 waves
+// Ray queues are split into NSHARD independent sub-queues, each with its own fill count and
+// dequeue head on its own 128-byte line: one device-scope atomic word sustains only ~90
+// operations per microsecond, and a 1080p frame needs ~32k wave-granular pushes and pops per
+// bounce.  Wave-sized chunk c of a producer goes to shard c % NSHARD.
+constexpr int NSHARD = 16;
+constexpr int CTL_STRIDE = 32;      // words between counters (128 bytes)
 constexpr float HIT_MIN_INIT = 100000.0f;   // frag:633,689
 
 // ------------------------------------------------------------------ small device helpers
@@ -409,10 +416,11 @@ __device__ __forceinline__ void store_path(const PathSoA &Q, uint32_t slot, cons
 }
 
 // generate: one wave per 8x8 pixel tile; writes the camera rays of one frame into queue 0
-// (slot = position in tile order, so a wave of the extend stage starts on a coherent tile)
-// and clears the frame's sample image.
+// (a tile stays together in one chunk, so a wave of the extend stage starts on a coherent
+// tile) and clears the frame's sample image.
 __global__ __launch_bounds__(BLOCK) void k_generate(const FrameD F, const float randOrigin, const PathSoA Q,
-                                                    uint32_t *__restrict__ qcount, float *__restrict__ cur) {
+                                                    const uint32_t cap, uint32_t *__restrict__ qcount,
+                                                    float *__restrict__ cur) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     uint32_t px, py;
@@ -423,55 +431,63 @@ __global__ __launch_bounds__(BLOCK) void k_generate(const FrameD F, const float 
         const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
         cur[o3] = 0.0f; cur[o3 + 1] = 0.0f; cur[o3 + 2] = 0.0f;
     }
-    const uint32_t slot = wave_push(qcount, valid);
+    const uint32_t shard = (uint32_t)tile % NSHARD;
+    const uint32_t slot = shard * cap + wave_push(qcount + shard * CTL_STRIDE, valid);
     if (valid) store_path(Q, slot, p, (py << 16) | px);
 }
 
-// extend: persistent waves pull batches of 64 rays from the queue until it is empty.
+// extend: persistent waves pull chunks of 64 rays from the sharded queue until every shard is
+// empty.  A wave starts on its own shard and moves on when that one is drained.
 template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA Q, const uint32_t *__restrict__ qcount,
-                                                  uint32_t *__restrict__ qhead, float *__restrict__ hitT,
-                                                  uint32_t *__restrict__ hitTri, WorkCounters *__restrict__ wc) {
+__global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA Q, const uint32_t cap,
+                                                  const uint32_t *__restrict__ qcount, uint32_t *__restrict__ qhead,
+                                                  float *__restrict__ hitT, uint32_t *__restrict__ hitTri,
+                                                  WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n = *qcount;
-    uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
-    while (true) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(qhead, 64u);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        const uint32_t slot = base + lane;
-        if (slot < n) {
-            const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
-            const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
-            float t; uint32_t tri;
-            closest_triangle<CULL, COUNT>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
-            hitT[slot] = t;
-            hitTri[slot] = tri;
-            cRays++;
-            if (COUNT && tri != REF_NONE) cHit++;
+    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    uint32_t cNode = 0, cTri = 0, cHit = 0;
+    for (uint32_t k = 0; k < NSHARD; k++) {
+        const uint32_t shard = (wave + k) % NSHARD;
+        const uint32_t n = qcount[shard * CTL_STRIDE];
+        while (true) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(qhead + shard * CTL_STRIDE, 64u);
+            base = __shfl(base, 0);
+            if (base >= n) break;
+            const uint32_t idx = base + lane;
+            if (idx < n) {
+                const uint32_t slot = shard * cap + idx;
+                const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
+                const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
+                float t; uint32_t tri;
+                closest_triangle<CULL, COUNT>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
+                hitT[slot] = t;
+                hitTri[slot] = tri;
+                if (COUNT && tri != REF_NONE) cHit++;
+            }
         }
     }
-    flush_counters(wc, cRays, cNode, cTri, cHit);
+    if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
 }
 
 // shade: one thread per ray of the current queue; finished paths write their sample,
 // continuing paths are compacted into the next queue.
 __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F, const int bounce, const uint32_t loopNum,
-                                                 const PathSoA Qin, const uint32_t *__restrict__ qcountIn,
+                                                 const PathSoA Qin, const uint32_t cap, const uint32_t *__restrict__ qcountIn,
                                                  const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri,
                                                  const PathSoA Qout, uint32_t *__restrict__ qcountOut,
                                                  float *__restrict__ cur) {
-    const uint32_t n = *qcountIn;
     const uint32_t stride = gridDim.x * BLOCK;
-    // every wave runs the same number of iterations so that wave_push sees whole waves
-    const uint32_t iters = (n + stride - 1) / stride;
-    for (uint32_t it = 0; it < iters; it++) {
-        const uint32_t slot = it * stride + blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t total = NSHARD * cap;        // cap is a multiple of 64: a wave never straddles shards
+    for (uint32_t v0 = blockIdx.x * BLOCK; v0 < total; v0 += stride) {
+        const uint32_t v = v0 + threadIdx.x;
+        const uint32_t shardIn = v / cap, idx = v - shardIn * cap;
+        const bool live = (v < total) && (idx < qcountIn[shardIn * CTL_STRIDE]);
         bool goOn = false;
         Path p; uint32_t pix = 0;
-        if (slot < n) {
+        if (live) {
+            const uint32_t slot = v;
             p.o = rtm::mk(Qin.ox[slot], Qin.oy[slot], Qin.oz[slot]);
             p.d = rtm::mk(Qin.dx[slot], Qin.dy[slot], Qin.dz[slot]);
             p.thr = rtm::mk(Qin.tr[slot], Qin.tg[slot], Qin.tb[slot]);
@@ -487,15 +503,24 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
                 cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
             }
         }
-        const uint32_t outSlot = wave_push(qcountOut, goOn);
+        const uint32_t shardOut = (v >> 6) % NSHARD;
+        const uint32_t outSlot = shardOut * cap + wave_push(qcountOut + shardOut * CTL_STRIDE, goOn);
         if (goOn) store_path(Qout, outSlot, p, pix);
     }
 }
 
 // accumulate: frag:697 (fp32 history) and the plain sum.
+// Thread 0 also adds the frame's ray count (the fill counts of all queues) to the counters.
 __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ cur, float *__restrict__ sum,
-                                                      float *__restrict__ mean, const size_t nfloats, const int loopNum) {
+                                                      float *__restrict__ mean, const size_t nfloats, const int loopNum,
+                                                      const uint32_t *__restrict__ qcounts, const int nqueues,
+                                                      WorkCounters *__restrict__ wc) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) {
+        unsigned long long rays = 0;
+        for (int q = 0; q < nqueues * NSHARD; q++) rays += qcounts[q * CTL_STRIDE];
+        atomicAdd(&wc->rays, rays);
+    }
     if (i >= nfloats) return;
     const float n = (float)loopNum;
     const float wa = 1.0f / n, wb = (float)(loopNum - 1) / n;
@@ -564,7 +589,9 @@ struct RtContext {
     float *dPathMem = nullptr;      // 2 x 11 arrays of P words
     PathSoA q[2]{};
     float *dHitT = nullptr; uint32_t *dHitTri = nullptr;
-    uint32_t *dQueueCtl = nullptr;  // per frame slot: counts[RT_MAX_BOUNCES+1], heads[RT_MAX_BOUNCES]
+    uint32_t *dQueueCtl = nullptr;  // fill counts and dequeue heads of the sharded queues
+    uint32_t queueCap = 0;          // slots per shard (multiple of 64)
+    int extendBlocksPerCU = 7;
     float *dRandOrigin = nullptr; int randCap = 0;
     WorkCounters *dCounters = nullptr;
     uint64_t frames = 0;
@@ -591,7 +618,9 @@ int fail(RtContext *ctx, int code, const std::string &msg) {
             return fail((ctx), RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
-constexpr int QCTL_WORDS = 2 * RT_MAX_BOUNCES + 2;     // counts[0..B], heads[0..B-1], padding
+// fill counts of queues 0..B and dequeue heads of queues 0..B-1, NSHARD each, one per 128-byte line
+constexpr int QCTL_COUNTS = (RT_MAX_BOUNCES + 1) * NSHARD * CTL_STRIDE;
+constexpr int QCTL_WORDS = QCTL_COUNTS + RT_MAX_BOUNCES * NSHARD * CTL_STRIDE;
 
 hipEvent_t take_event(RtContext *ctx) {
     if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
@@ -733,8 +762,11 @@ int rt_create(RtContext **out, int width, int height, int device) {
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) ctx->numCU = prop.multiProcessorCount;
-    const size_t P = (size_t)width * height;
-    const size_t img = P * 3 * sizeof(float);
+    const size_t img = (size_t)width * height * 3 * sizeof(float);
+    // queue capacity: 8x8 tiles dealt round-robin to the shards
+    const size_t tilesTotal = (size_t)((width + 7) / 8) * ((height + 7) / 8);
+    ctx->queueCap = (uint32_t)(((tilesTotal + NSHARD - 1) / NSHARD) * 64);
+    const size_t P = (size_t)ctx->queueCap * NSHARD;     // slots per queue
     if (e == hipSuccess) e = hipMalloc(&ctx->dSumOwned, img);
     if (e == hipSuccess) e = hipMalloc(&ctx->dMean, img);
     if (e == hipSuccess) e = hipMalloc(&ctx->dCur, img);
@@ -749,6 +781,10 @@ int rt_create(RtContext **out, int width, int height, int device) {
         return fail(nullptr, RT_E_HIP, msg);
     }
     ctx->dSum = ctx->dSumOwned;
+    if (const char *env = getenv("RT_AMD_EXTEND_BLOCKS_PER_CU")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
+    }
     for (int b = 0; b < 2; b++) {
         float *base = ctx->dPathMem + (size_t)b * 11 * P;
         PathSoA &q = ctx->q[b];
@@ -923,30 +959,33 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     }
 
     // wavefront pipeline, one frame at a time
-    const int extendBlocks = ctx->numCU * 4;        // persistent: 16 waves per CU
-    const int shadeBlocks = ctx->numCU * 8;
+    const int extendBlocks = ctx->numCU * ctx->extendBlocksPerCU;   // persistent waves
+    const uint32_t cap = ctx->queueCap;
+    const int shadeBlocks = (int)std::min<size_t>(((size_t)cap * NSHARD + BLOCK - 1) / BLOCK, (size_t)ctx->numCU * 32);
     const size_t nfloats = (size_t)ctx->width * ctx->height * 3;
     const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
-    uint32_t *counts = ctx->dQueueCtl, *heads = ctx->dQueueCtl + RT_MAX_BOUNCES + 1;
+    uint32_t *counts = ctx->dQueueCtl, *heads = ctx->dQueueCtl + QCTL_COUNTS;
+    const int qstride = NSHARD * CTL_STRIDE;
     for (int f = 0; f < count; f++) {
         const int loopNum = first_loopnum + f;
         HIP_TRY(ctx, hipMemsetAsync(ctx->dQueueCtl, 0, QCTL_WORDS * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_generate, dim3(tileBlocks), dim3(BLOCK), 0, st, F, rand_origin[f], ctx->q[0], counts + 0, ctx->dCur);
+        hipLaunchKernelGGL(k_generate, dim3(tileBlocks), dim3(BLOCK), 0, st, F, rand_origin[f], ctx->q[0], cap, counts, ctx->dCur);
         for (int b = 0; b < F.maxBounces; b++) {
             const PathSoA &qin = ctx->q[b & 1], &qout = ctx->q[(b + 1) & 1];
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, st));
-#define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, counts + b, heads + b, ctx->dHitT, ctx->dHitTri, ctx->dCounters)
+#define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters)
             if (cull) { if (cnt) LAUNCH_EXT(true, true); else LAUNCH_EXT(true, false); }
             else { if (cnt) LAUNCH_EXT(false, true); else LAUNCH_EXT(false, false); }
 #undef LAUNCH_EXT
             HIP_TRY(ctx, hipEventRecord(e1, st));
             ctx->pendingEvents.emplace_back(e0, e1);
-            hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, qin, counts + b,
-                               ctx->dHitT, ctx->dHitTri, qout, counts + b + 1, ctx->dCur);
+            hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, qin, cap, counts + b * qstride,
+                               ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum);
+        hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum,
+                           counts, F.maxBounces, ctx->dCounters);
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->frames += (uint64_t)count;
