@@ -1,0 +1,140 @@
+"""BVH construction: the library's builder (own introselect) against the oracle's restatement
+of BVH.h (which calls std::nth_element as the reference does), bit for bit, and both against
+the answers recorded from the reference builder for its bundled scene."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import raytracing_amd as rt
+import scenes
+
+
+def _same(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+def test_struct_sizes_match_reference():
+    lib = ol.load()
+    assert lib.bvh_oracle_sizeof_triangle() == 144 == rt.TRIANGLE_DTYPE.itemsize
+    assert lib.bvh_oracle_sizeof_node() == 36 == rt.NODE_DTYPE.itemsize
+
+
+def test_demo_scene_known_answers(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "demo_bvh_known_answers.json")))
+    tris0 = scenes.demo().triangles()
+    assert tris0.shape[0] == ka["triangles"]
+    for build in (rt.bvh_build, ol.bvh_build):
+        tris, nodes = build(tris0)
+        assert nodes.shape[0] == ka["nodes"]
+        for k, mx, mn, cnt, off, ax in ka["node_rows"]:
+            nd = nodes[k]
+            assert list(nd["maxBound"]) == mx and list(nd["minBound"]) == mn, k
+            assert (nd["triangleNum"], nd["offsetOrRc"], nd["axis"]) == (cnt, off, ax), k
+        leaves = nodes[nodes["triangleNum"] == 1]
+        assert list(leaves["offsetOrRc"]) == list(range(32))        # DFS leaf ordinal
+        assert [i for i in range(32) if tris[i]["ka"].sum() > 0] == ka["emissive_triangle_indices"]
+    x, y = rt.C.c_int(), rt.C.c_int()
+    rt.lib.rt_texture_dims(32, 33, rt.C.byref(x), rt.C.byref(y))
+    assert [x.value * 33, y.value] == ka["texture_dims"]["triangles"]
+    rt.lib.rt_texture_dims(63, 9, rt.C.byref(x), rt.C.byref(y))
+    assert [x.value * 9, y.value] == ka["texture_dims"]["nodes"]
+
+
+@pytest.mark.parametrize("n,snap", [(1, None), (2, None), (3, None), (4, 1.0), (7, 0.5), (16, 2.0), (17, None),
+                                    (1000, None), (1000, 0.5), (1000, 4.0), (20000, 0.25), (20000, None)])
+def test_builder_equals_oracle(n, snap):
+    tris0 = scenes.random_triangles(n, 1000 + n, snap=snap)
+    a_t, a_n = rt.bvh_build(tris0)
+    b_t, b_n = ol.bvh_build(tris0)
+    assert a_n.shape[0] == 2 * n - 1
+    assert _same(a_n, b_n)
+    assert _same(a_t, b_t)
+
+
+def test_builder_equals_oracle_all_centres_equal():
+    # every comparison is a tie: the permutation is decided by the selection routine alone
+    tris0 = scenes.random_triangles(513, 5)
+    tris0["v"][:] = tris0["v"][0]
+    a_t, a_n = rt.bvh_build(tris0)
+    b_t, b_n = ol.bvh_build(tris0)
+    assert _same(a_n, b_n) and _same(a_t, b_t)
+
+
+def test_builder_equals_oracle_synthetic_mesh():
+    sc = rt.Scene()
+    sc.push_synthetic(0, 4, 1, 12345)       # room + 5120-triangle icosphere
+    tris0 = sc.triangles()
+    assert tris0.shape[0] == 20 + 20 * 4 ** 4
+    a_t, a_n = rt.bvh_build(tris0)
+    b_t, b_n = ol.bvh_build(tris0)
+    assert _same(a_n, b_n) and _same(a_t, b_t)
+
+
+def _killer(n):
+    """Median-of-3 killer sequence (Musser): drives introselect into its heap-select fallback."""
+    k = n // 2
+    a = np.zeros(n, dtype=np.float32)
+    for i in range(1, k + 1):
+        if i % 2 == 1:
+            a[i - 1] = i
+            a[i] = k + i
+        a[k + i - 1] = 2 * i
+    return a
+
+
+@pytest.mark.parametrize("case", ["random", "ties", "sorted", "reversed", "killer", "organ", "two_values"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 16, 17, 100, 1024, 5000])
+def test_selection_permutation_equals_libstdcxx(case, n):
+    rng = np.random.default_rng(n * 7 + len(case))
+    if case == "random":
+        keys = rng.normal(size=n)
+    elif case == "ties":
+        keys = rng.integers(0, max(2, n // 8), size=n)
+    elif case == "sorted":
+        keys = np.arange(n)
+    elif case == "reversed":
+        keys = np.arange(n)[::-1]
+    elif case == "killer":
+        keys = _killer(n) if n >= 4 else np.arange(n)
+    elif case == "organ":
+        keys = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]])
+    else:
+        keys = rng.integers(0, 2, size=n)
+    keys = np.ascontiguousarray(keys, dtype=np.float32)
+    lib = ol.load()
+    for nth in sorted({0, n // 2, n - 1, n // 3, n}):
+        k1, i1 = keys.copy(), np.arange(n, dtype=np.int32)
+        k2, i2 = keys.copy(), np.arange(n, dtype=np.int32)
+        if nth < n or n == 0:
+            lib.bvh_oracle_nth_element(k1.ctypes.data, i1.ctypes.data, n, nth)
+        rc = rt.lib.rt_selftest_nth_element(k2.ctypes.data, i2.ctypes.data, n, nth)
+        assert rc == 0
+        if nth == n:
+            assert np.array_equal(i2, np.arange(n))     # nth == last: untouched, as std::nth_element
+        else:
+            assert np.array_equal(i1, i2), (case, n, nth)
+            assert np.array_equal(k1, k2)
+
+
+def test_texture_packing_equals_oracle():
+    tris, nodes = rt.bvh_build(scenes.random_triangles(50, 9))
+    a = rt.pack_textures(tris, nodes)
+    b = ol.pack_textures(tris, nodes)
+    assert a[1] == b[1] and a[3] == b[3]
+    n, m = tris.shape[0], nodes.shape[0]
+    assert np.array_equal(a[0][:n * 33], b[0][:n * 33])         # padding differs by design (0 vs NaN)
+    assert np.array_equal(a[2][:m * 9], b[2][:m * 9])
+    assert np.isnan(b[0][n * 33:]).all() and (a[0][n * 33:] == 0).all()
+
+
+def test_builder_rejects_bad_arguments():
+    t = np.zeros(1, dtype=rt.TRIANGLE_DTYPE)
+    nodes = np.zeros(1, dtype=rt.NODE_DTYPE)
+    cnt = rt.C.c_int64()
+    assert rt.lib.rt_bvh_build(t.ctypes.data, 0, nodes.ctypes.data, 1, rt.C.byref(cnt)) == -1
+    t3 = np.zeros(3, dtype=rt.TRIANGLE_DTYPE)
+    assert rt.lib.rt_bvh_build(t3.ctypes.data, 3, nodes.ctypes.data, 1, rt.C.byref(cnt)) == -1
+    assert b"node_capacity" in rt.lib.rt_last_error(None)
