@@ -112,84 +112,134 @@ __device__ __forceinline__ float triangle_test(const float4 q0, const float4 q1,
     return t - 0.00001f;
 }
 
-// The traversal loop of hitBVH, frag:380-421.  Visits children in the reference's order
-// (near child by dirIsNeg[axis], far child deferred on a LIFO stack) and keeps the closest
-// hit with the same strict comparison, so ties resolve as in the reference.
+// The traversal loop of hitBVH, frag:380-421, as a per-lane state machine.  It visits children
+// in the reference's order (near child by dirIsNeg[axis], far child deferred on a LIFO stack)
+// and keeps the closest hit with the same strict comparison, so ties resolve as in the
+// reference.  `cur` is the next thing to process: an interior node index, LEAF_BIT|triangle,
+// or REF_NONE when the ray is finished.
 // stack: this lane's LDS column, entry i at stack[i*stride].
 // CULL: additionally skip a box when a lower bound of its entry distance, computed against
 // the box grown by eps, lies beyond the closest hit so far; no triangle in such a box can
 // pass `dis_t < ray.hitMin` (frag:396), so the result is unchanged.
 template <bool CULL, bool COUNT>
+struct Trav {
+    vec3 o, d, inv;
+    float ex, ey, ez, hitCull;
+    float hitMin;
+    uint32_t best;
+    uint32_t cur;
+    int sp;
+    bool nx, ny, nz;
+
+    __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
+        o = o_; d = d_;
+        hitMin = HIT_MIN_INIT;
+        best = REF_NONE;
+        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);         // frag:376
+        nx = inv.x < 0.0f; ny = inv.y < 0.0f; nz = inv.z < 0.0f;    // frag:378
+        ex = ey = ez = hitCull = 0.0f;
+        if (CULL) {
+            const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+            const float eps = rtm::madd(oM, 1.0f / 1024.0f, S.cullEps);
+            ex = eps * fabsf(inv.x); ey = eps * fabsf(inv.y); ez = eps * fabsf(inv.z);
+            hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+        }
+        sp = 0;
+        cur = S.rootRef;
+        if (cur != REF_NONE) {
+            float a, b, c;
+            const bool pass = slab_test(S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2],
+                                        o, inv, nx, ny, nz, a, b, c);
+            if (COUNT) nNode++;
+            if (!pass) cur = REF_NONE;
+        }
+    }
+
+    __device__ __forceinline__ bool at_interior() const { return (int32_t)cur >= 0; }          // not LEAF, not NONE
+    __device__ __forceinline__ bool at_leaf() const { return (cur & LEAF_BIT) && cur != REF_NONE; }
+    __device__ __forceinline__ bool done() const { return cur == REF_NONE; }
+
+    __device__ __forceinline__ void pop(const uint32_t *stack, const int stride) {
+        cur = REF_NONE;
+        if (sp > 0) cur = stack[(--sp) * stride];
+    }
+
+    // cur is an interior node: test both children, descend / defer / pop (frag:386-420)
+    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t &nNode) {
+        const float4 *rec = S.nodes + (size_t)cur * 4;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        float lnx, lny, lnz, rnx, rny, rnz;
+        bool passL = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, lnx, lny, lnz);
+        bool passR = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, nx, ny, nz, rnx, rny, rnz);
+        if (COUNT) nNode += 2;
+        if (CULL) {
+            const float lb = fmaxf(lnx - ex, fmaxf(lny - ey, lnz - ez));
+            const float rb = fmaxf(rnx - ex, fmaxf(rny - ey, rnz - ez));
+            if (lb > hitCull) passL = false;
+            if (rb > hitCull) passR = false;
+        }
+        const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+        const bool negAxis = (axis == 0u) ? nx : ((axis == 1u) ? ny : nz);      // frag:407
+        const uint32_t nearRef = negAxis ? right : left;
+        const uint32_t farRef = negAxis ? left : right;
+        const bool nearPass = negAxis ? passR : passL;
+        const bool farPass = negAxis ? passL : passR;
+        if (nearPass) {
+            cur = nearRef;
+            if (farPass) stack[(sp++) * stride] = farRef;
+        } else if (farPass) {
+            cur = farRef;
+        } else {
+            pop(stack, stride);
+        }
+    }
+
+    // cur is a leaf: test its triangle, keep it if closer (frag:390-403), then pop
+    __device__ __forceinline__ void leaf_step(const SceneD &S, const uint32_t *stack, const int stride, uint32_t &nTri) {
+        const uint32_t ti = cur & ~LEAF_BIT;
+        const float4 *rec = S.tris + (size_t)ti * 4;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        const float dis = triangle_test(q0, q1, q2, q3, o, d);
+        if (COUNT) nTri++;
+        if (dis > 0.0f && dis < hitMin) {           // frag:396
+            hitMin = dis;
+            best = ti;
+            if (CULL) hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+        }
+        pop(stack, stride);
+    }
+};
+
+// Every lane of a wave that is still working is either at an interior node or at a leaf.
+// Measured on MI355X: making lanes wait at a leaf so that triangle tests run in batches
+// (while-while traversal) is slower at every batch size (1.22 -> 0.66 Grays/s from batch 1 to
+// 64 on the 1.31M-triangle scene); the cost is per wave iteration, not per issued instruction.
+
+template <bool CULL, bool COUNT>
+__device__ __forceinline__ void wave_advance(Trav<CULL, COUNT> &tv, const SceneD &S, uint32_t *stack, const int stride,
+                                             uint32_t &nNode, uint32_t &nTri, unsigned long long mInterior,
+                                             unsigned long long mLeaf) {
+    // every working lane advances by one step per iteration
+    if (tv.at_interior()) tv.node_step(S, stack, stride, nNode);
+    else if (tv.at_leaf()) tv.leaf_step(S, stack, stride, nTri);
+}
+
+// Runs the rays of the calling lanes to completion (all lanes leave together).
+template <bool CULL, bool COUNT>
 __device__ __forceinline__ void closest_triangle(const SceneD &S, const vec3 o, const vec3 d,
                                                  uint32_t *stack, const int stride,
                                                  float &tOut, uint32_t &triOut,
                                                  uint32_t &nNode, uint32_t &nTri) {
-    float hitMin = HIT_MIN_INIT;
-    uint32_t best = REF_NONE;
-    const vec3 inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);      // frag:376
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;  // frag:378
-    float ex = 0.0f, ey = 0.0f, ez = 0.0f, hitCull = 0.0f;
-    if (CULL) {
-        const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-        const float eps = rtm::madd(oM, 1.0f / 1024.0f, S.cullEps);
-        ex = eps * fabsf(inv.x); ey = eps * fabsf(inv.y); ez = eps * fabsf(inv.z);
-        hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+    Trav<CULL, COUNT> tv;
+    tv.begin(S, o, d, nNode);
+    while (true) {
+        const unsigned long long mI = __ballot(tv.at_interior());
+        const unsigned long long mL = __ballot(tv.at_leaf());
+        if ((mI | mL) == 0ull) break;
+        wave_advance(tv, S, stack, stride, nNode, nTri, mI, mL);
     }
-    uint32_t cur = S.rootRef;
-    if (cur != REF_NONE) {
-        float a, b, c;
-        const bool pass = slab_test(S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2],
-                                    o, inv, nx, ny, nz, a, b, c);
-        if (COUNT) nNode++;
-        if (!pass) cur = REF_NONE;
-    }
-    int sp = 0;
-    while (cur != REF_NONE) {
-        if (cur & LEAF_BIT) {
-            const uint32_t ti = cur & ~LEAF_BIT;
-            const float4 *rec = S.tris + (size_t)ti * 4;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            const float dis = triangle_test(q0, q1, q2, q3, o, d);
-            if (COUNT) nTri++;
-            if (dis > 0.0f && dis < hitMin) {           // frag:396
-                hitMin = dis;
-                best = ti;
-                if (CULL) hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-            }
-            cur = REF_NONE;
-            if (sp > 0) cur = stack[(--sp) * stride];
-        } else {
-            const float4 *rec = S.nodes + (size_t)cur * 4;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            float lnx, lny, lnz, rnx, rny, rnz;
-            bool passL = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, lnx, lny, lnz);
-            bool passR = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, nx, ny, nz, rnx, rny, rnz);
-            if (COUNT) nNode += 2;
-            if (CULL) {
-                const float lb = fmaxf(lnx - ex, fmaxf(lny - ey, lnz - ez));
-                const float rb = fmaxf(rnx - ex, fmaxf(rny - ey, rnz - ez));
-                if (lb > hitCull) passL = false;
-                if (rb > hitCull) passR = false;
-            }
-            const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
-            const bool negAxis = (axis == 0u) ? nx : ((axis == 1u) ? ny : nz);      // frag:407
-            const uint32_t nearRef = negAxis ? right : left;
-            const uint32_t farRef = negAxis ? left : right;
-            const bool nearPass = negAxis ? passR : passL;
-            const bool farPass = negAxis ? passL : passR;
-            if (nearPass) {
-                cur = nearRef;
-                if (farPass) stack[(sp++) * stride] = farRef;
-            } else if (farPass) {
-                cur = farRef;
-            } else {
-                cur = REF_NONE;
-                if (sp > 0) cur = stack[(--sp) * stride];
-            }
-        }
-    }
-    tOut = hitMin;
-    triOut = best;
+    tOut = tv.hitMin;
+    triOut = tv.best;
 }
 
 struct Path {
@@ -436,35 +486,65 @@ __global__ __launch_bounds__(BLOCK) void k_generate(const FrameD F, const float 
     if (valid) store_path(Q, slot, p, (py << 16) | px);
 }
 
-// extend: persistent waves pull chunks of 64 rays from the sharded queue until every shard is
-// empty.  A wave starts on its own shard and moves on when that one is drained.
+// extend: persistent waves pull rays from the sharded queue until every shard is empty.  A lane
+// that finishes its ray does not wait for the slowest lane of its wave: as soon as S.refill lanes
+// are idle the wave reserves that many queue entries with one atomic and the idle lanes start
+// on new rays while the others keep traversing (traversal lengths differ by several times
+// between neighbouring rays, and a wave pays for its longest lane).
+
 template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA Q, const uint32_t cap,
                                                   const uint32_t *__restrict__ qcount, uint32_t *__restrict__ qhead,
                                                   float *__restrict__ hitT, uint32_t *__restrict__ hitTri,
                                                   WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t cNode = 0, cTri = 0, cHit = 0;
-    for (uint32_t k = 0; k < NSHARD; k++) {
-        const uint32_t shard = (wave + k) % NSHARD;
-        const uint32_t n = qcount[shard * CTL_STRIDE];
-        while (true) {
+    Trav<CULL, COUNT> tv;
+    tv.cur = REF_NONE;
+    bool have = false;
+    uint32_t slot = 0;
+    uint32_t k = 0, shard = wave % NSHARD;
+    uint32_t n = qcount[shard * CTL_STRIDE];
+    bool more = true;                                   // wave-uniform: some shard may still hold rays
+    while (true) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (more && (nIdle >= (uint32_t)S.refill)) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(qhead + shard * CTL_STRIDE, 64u);
-            base = __shfl(base, 0);
-            if (base >= n) break;
-            const uint32_t idx = base + lane;
-            if (idx < n) {
-                const uint32_t slot = shard * cap + idx;
+            const int leader = __ffsll((long long)idle) - 1;
+            if ((int)lane == leader) base = atomicAdd(qhead + shard * CTL_STRIDE, nIdle);
+            base = __shfl(base, leader);
+            if (base >= n) {                            // this shard is drained: move on
+                k++;
+                if (k == NSHARD) more = false;
+                else { shard = (wave + k) % NSHARD; n = qcount[shard * CTL_STRIDE]; }
+                continue;
+            }
+            const uint32_t idx = base + (uint32_t)__popcll(idle & below);
+            if (!have && idx < n) {
+                slot = shard * cap + idx;
                 const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
                 const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
-                float t; uint32_t tri;
-                closest_triangle<CULL, COUNT>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
-                hitT[slot] = t;
-                hitTri[slot] = tri;
-                if (COUNT && tri != REF_NONE) cHit++;
+                tv.begin(S, o, d, cNode);
+                have = true;
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+        if (have) {
+            if (tv.at_interior()) tv.node_step(S, stack, BLOCK, cNode);
+            else if (tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
+            if (tv.done()) {
+                hitT[slot] = tv.hitMin;
+                hitTri[slot] = tv.best;
+                if (COUNT && tv.best != REF_NONE) cHit++;
+                have = false;
             }
         }
     }
@@ -714,6 +794,8 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
     if (n == 1 && nodes[0].offsetOrRc != 0) return fail(ctx, RT_E_INVALID, "scene upload: single leaf must reference triangle 0");
     S.cullEps = maxAbs * (1.0f / 1024.0f);
     S.stackEntries = maxDepth + 1;
+    S.refill = 16;
+    if (const char *env = getenv("RT_AMD_REFILL")) { const int v = atoi(env); if (v >= 1 && v <= 64) S.refill = v; }
     return RT_OK;
 }
 

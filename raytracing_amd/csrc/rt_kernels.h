@@ -43,6 +43,7 @@ struct SceneD {
     uint32_t rootRef;       // LEAF_BIT|0 for a one-triangle scene, 0 otherwise, REF_NONE if empty
     float cullEps;          // 2^-10 * largest |coordinate| of the root box
     int32_t stackEntries;   // LDS stack slots per lane (tree height)
+    int32_t refill;         // idle lanes of a wave that trigger a fetch of new rays
 };
 
 struct FrameD {

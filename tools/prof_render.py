@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Small render driver for profiling runs (rocprofv3 ... -- python3 tools/prof_render.py ...):
+builds a benchmark scene, renders a few frames through the C ABI and prints Mrays/s.  No torch."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracing_amd as rt  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", type=int, default=0)
+    ap.add_argument("--level", type=int, default=8)
+    ap.add_argument("--copies", type=int, default=1)
+    ap.add_argument("--demo", action="store_true")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--no-cull", action="store_true")
+    ap.add_argument("--count", action="store_true")
+    a = ap.parse_args()
+    sc = rt.Scene()
+    if a.demo:
+        sc.push_demo()
+    else:
+        sc.push_synthetic(a.kind, a.level, a.copies, 12345)
+    r = rt.make_renderer(sc, a.width, a.height, 0, max_bounces=a.bounces, pipeline=a.pipeline,
+                         cull=not a.no_cull, count_work=a.count)
+    ro = rt.rand_origins(20221003, a.warmup + a.frames)
+    if a.warmup:
+        r.render(1, ro[:a.warmup])
+    r.synchronize()
+    r.reset()
+    t0 = time.perf_counter()
+    r.render(a.warmup + 1, ro[a.warmup:])
+    r.synchronize()
+    dt = time.perf_counter() - t0
+    st = r.stats()
+    ms, n = r.kernel_time()
+    print(f"frames {a.frames} rays {st['rays']} wall {dt * 1e3:.2f} ms -> {st['rays'] / dt / 1e6:.1f} Mrays/s; "
+          f"dominant kernel {ms:.2f} ms over {n} launches; nodes/ray {st['node_tests'] / max(st['rays'], 1):.1f} "
+          f"tris/ray {st['tri_tests'] / max(st['rays'], 1):.2f}")
+
+
+if __name__ == "__main__":
+    main()
