@@ -85,6 +85,8 @@ typedef struct RtStats {
     uint64_t tri_tests;     /* triangles tested (hitTriangle, frag:255-278) */
     uint64_t tri_hits;      /* rays whose closest BVH hit was a triangle (frag:457) */
     uint64_t frames;        /* frames rendered */
+    uint64_t retraced;      /* rays whose search-index result could not be proven equal to the
+                               reference's and that were traced again in the reference's order */
 } RtStats;
 
 /* Render options; rt_default_options() gives the reference's behaviour. */
@@ -94,6 +96,11 @@ typedef struct RtOptions {
     int32_t cull;           /* 1: skip boxes that provably cannot hold a closer hit (same image);
                                0: visit exactly the boxes the reference visits */
     int32_t count_work;     /* 1: maintain node_tests/tri_tests/tri_hits (slower kernels) */
+    int32_t accel;          /* 1 (wavefront pipeline only): find the closest accepted triangle through
+                               a SAH search index built at upload, prove with one exact box test that
+                               the reference's traversal reaches it, and re-trace in the reference's
+                               order the rays for which the proof fails (same image);
+                               0: always traverse the reference's tree in the reference's order */
 } RtOptions;
 #define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
 #define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */

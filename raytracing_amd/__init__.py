@@ -39,12 +39,12 @@ assert SPHERE_DTYPE.itemsize == 40 and CAMERA_DTYPE.itemsize == 72
 
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_tests", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("tri_hits", C.c_uint64), ("frames", C.c_uint64)]
+                ("tri_hits", C.c_uint64), ("frames", C.c_uint64), ("retraced", C.c_uint64)]
 
 
 class RtOptions(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
-                ("count_work", C.c_int32)]
+                ("count_work", C.c_int32), ("accel", C.c_int32)]
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
@@ -243,8 +243,8 @@ class Renderer:
     def set_stream(self, stream_handle):
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
-    def set_options(self, max_bounces=4, pipeline=PIPELINE_WAVEFRONT, cull=True, count_work=False):
-        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work))
+    def set_options(self, max_bounces=4, pipeline=PIPELINE_WAVEFRONT, cull=True, count_work=False, accel=True):
+        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 
     def upload(self, tris, nodes):

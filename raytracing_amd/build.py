@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_amd.so")
-SOURCES = ["rt_device.hip", "rt_bvh.cpp", "rt_host.cpp", "rt_scene.cpp"]
-HEADERS = ["rt_internal.h", "rt_kernels.h", "rt_math.h", os.path.join("..", "..", "include", "rt_amd.h")]
+SOURCES = ["rt_device.hip", "rt_bvh.cpp", "rt_host.cpp", "rt_scene.cpp", "rt_accel.cpp"]
+HEADERS = ["rt_internal.h", "rt_kernels.h", "rt_math.h", "rt_accel.h", os.path.join("..", "..", "include", "rt_amd.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_accel.h"
 #include "rt_internal.h"
 #include "rt_kernels.h"
 
@@ -240,6 +241,129 @@ __device__ __forceinline__ void closest_triangle(const SceneD &S, const vec3 o, 
     }
     tOut = tv.hitMin;
     triOut = tv.best;
+}
+
+// ---------------------------------------------------------------- search index traversal
+
+__device__ __forceinline__ bool finite3(const vec3 v) {
+    return (fabsf(v.x) < INFINITY) && (fabsf(v.y) < INFINITY) && (fabsf(v.z) < INFINITY);
+}
+
+//
+// Finds the closest triangle that hitTriangle accepts, through the SAH index.  The index boxes
+// are grown (rt_accel.cpp), the box test below treats NaN as "inside", and a box is only
+// skipped when it starts beyond the closest hit so far by a margin, so no triangle that could
+// be accepted at a distance <= the final one is missed.  `tie` reports that two different
+// triangles were accepted at exactly the final distance (the reference keeps whichever it
+// meets first, which this search cannot tell).
+template <bool COUNT>
+struct FastTrav {
+    vec3 o, d, inv;
+    float hitMin, hitCull;
+    uint32_t best, cur;
+    int sp;
+    bool tie;
+
+    static __device__ __forceinline__ void box_span(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                                    const vec3 o, const vec3 inv, float &tn, float &tf) {
+        const float x0 = (mnx - o.x) * inv.x, x1 = (mxx - o.x) * inv.x;
+        const float y0 = (mny - o.y) * inv.y, y1 = (mxy - o.y) * inv.y;
+        const float z0 = (mnz - o.z) * inv.z, z1 = (mxz - o.z) * inv.z;
+        tn = fmaxf(fminf(x0, x1), fmaxf(fminf(y0, y1), fminf(z0, z1)));
+        tf = fminf(fmaxf(x0, x1), fminf(fmaxf(y0, y1), fmaxf(z0, z1)));
+    }
+    __device__ __forceinline__ bool box_live(float tn, float tf) const {
+        return !(tn > tf) && !(tf < 0.0f) && !(tn > hitCull);
+    }
+
+    __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
+        o = o_; d = d_;
+        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        hitMin = HIT_MIN_INIT;
+        hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+        best = REF_NONE; tie = false; sp = 0;
+        cur = S.arootRef;
+        float tn, tf;
+        box_span(S.arootMin[0], S.arootMin[1], S.arootMin[2], S.arootMax[0], S.arootMax[1], S.arootMax[2], o, inv, tn, tf);
+        if (COUNT) nNode++;
+        if (!box_live(tn, tf)) cur = REF_NONE;
+        // a ray with a zero, NaN or infinite direction component is not searched here at all
+        // (with NaN every box would count as hit); the caller sends it to the exact path
+        if (!usable(S)) cur = REF_NONE;
+    }
+    // rays this search may be used for: finite 1/d and an origin within the range the growth
+    // of the index boxes was sized for
+    __device__ __forceinline__ bool usable(const SceneD &S) const {
+        const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+        return finite3(inv) && (oM <= S.originLimit);
+    }
+    __device__ __forceinline__ bool at_interior() const { return (int32_t)cur >= 0; }
+    __device__ __forceinline__ bool at_leaf() const { return (cur & LEAF_BIT) && cur != REF_NONE; }
+    __device__ __forceinline__ bool done() const { return cur == REF_NONE; }
+    __device__ __forceinline__ void pop(const uint32_t *stack, const int stride) {
+        cur = REF_NONE;
+        if (sp > 0) cur = stack[(--sp) * stride];
+    }
+
+    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t &nNode) {
+        const float4 *rec = S.anodes + (size_t)cur * 4;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        float tnL, tfL, tnR, tfR;
+        box_span(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tnL, tfL);
+        box_span(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tnR, tfR);
+        if (COUNT) nNode += 2;
+        const bool hitL = box_live(tnL, tfL), hitR = box_live(tnR, tfR);
+        const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+        if (hitL && hitR) {
+            const bool leftFirst = !(tnR < tnL);
+            cur = leftFirst ? left : right;
+            stack[(sp++) * stride] = leftFirst ? right : left;
+        } else if (hitL) {
+            cur = left;
+        } else if (hitR) {
+            cur = right;
+        } else {
+            pop(stack, stride);
+        }
+    }
+
+    __device__ __forceinline__ void leaf_step(const SceneD &S, const uint32_t *stack, const int stride, uint32_t &nTri) {
+        const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            const uint32_t ti = S.atris[first + k];
+            const float4 *rec = S.tris + (size_t)ti * 4;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            const float dis = triangle_test(q0, q1, q2, q3, o, d);
+            if (COUNT) nTri++;
+            if (dis > 0.0f) {
+                if (dis < hitMin) {
+                    hitMin = dis; best = ti; tie = false;
+                    hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+                } else if (dis == hitMin && ti != best) {
+                    tie = true;
+                }
+            }
+        }
+        pop(stack, stride);
+    }
+};
+
+// The reference reaches triangle `tri` iff every box on the path from the root to its leaf
+// passes IntersectBound.  Those boxes are nested (each is the exact min/max of the triangles
+// below it), and for a ray with finite 1/d the entry distance (b_near - o)*inv can only
+// decrease and the exit distance only increase when a box grows, because fp32 subtraction and
+// multiplication are monotonic.  IntersectBound passes exactly when every entry distance is
+// <= every other axis' exit distance and all exit distances are > 0, so a pass at the leaf
+// implies a pass at every ancestor: testing the leaf's own box (the min/max of the triangle's
+// vertices, BVH.h:42-54) is enough.
+__device__ __forceinline__ bool verify_reference_reaches(const SceneD &S, const vec3 o, const vec3 inv, uint32_t tri) {
+    const float4 *rec = S.tris + (size_t)tri * 4;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    const float mnx = fminf(fminf(q0.x, q0.w), q1.z), mxx = fmaxf(fmaxf(q0.x, q0.w), q1.z);
+    const float mny = fminf(fminf(q0.y, q1.x), q1.w), mxy = fmaxf(fmaxf(q0.y, q1.x), q1.w);
+    const float mnz = fminf(fminf(q0.z, q1.y), q2.x), mxz = fmaxf(fmaxf(q0.z, q1.y), q2.x);
+    float a, b, c;
+    return slab_test(mnx, mny, mnz, mxx, mxy, mxz, o, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f, a, b, c);
 }
 
 struct Path {
@@ -551,6 +675,98 @@ __global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA 
     if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
 }
 
+// extend through the search index: same refill loop as k_extend, FastTrav instead of the
+// reference-order traversal.  A finished ray whose result cannot be proven equal to the
+// reference's (tie, non-finite 1/d, origin far outside the scene, or the reference not reaching
+// the triangle) is appended to the retry list and re-traced by k_extend_retry.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const PathSoA Q, const uint32_t cap,
+                                                       const uint32_t *__restrict__ qcount, uint32_t *__restrict__ qhead,
+                                                       float *__restrict__ hitT, uint32_t *__restrict__ hitTri,
+                                                       uint32_t *__restrict__ retryCount, uint32_t *__restrict__ retrySlots,
+                                                       WorkCounters *__restrict__ wc) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t cNode = 0, cTri = 0, cHit = 0;
+    FastTrav<COUNT> tv;
+    tv.cur = REF_NONE;
+    bool have = false;
+    uint32_t slot = 0;
+    uint32_t k = 0, shard = wave % NSHARD;
+    uint32_t n = qcount[shard * CTL_STRIDE];
+    bool more = true;
+    while (true) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (more && (nIdle >= (uint32_t)S.refill)) {
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)idle) - 1;
+            if ((int)lane == leader) base = atomicAdd(qhead + shard * CTL_STRIDE, nIdle);
+            base = __shfl(base, leader);
+            if (base >= n) {
+                k++;
+                if (k == NSHARD) more = false;
+                else { shard = (wave + k) % NSHARD; n = qcount[shard * CTL_STRIDE]; }
+                continue;
+            }
+            const uint32_t idx = base + (uint32_t)__popcll(idle & below);
+            if (!have && idx < n) {
+                slot = shard * cap + idx;
+                const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
+                const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
+                tv.begin(S, o, d, cNode);
+                have = true;
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+        if (have) {
+            if (tv.at_interior()) tv.node_step(S, stack, BLOCK, cNode);
+            else if (tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
+            if (tv.done()) {
+                bool exact = tv.tie || !tv.usable(S);
+                if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
+                hitT[slot] = tv.hitMin;
+                hitTri[slot] = tv.best;
+                if (exact) retrySlots[atomicAdd(retryCount, 1u)] = slot;
+                else if (COUNT && tv.best != REF_NONE) cHit++;
+                have = false;
+            }
+        }
+    }
+    if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
+}
+
+// Re-traces the rays of the retry list in the reference's order (normally a handful per frame).
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend_retry(const SceneD S, const PathSoA Q, const uint32_t *__restrict__ retryCount,
+                                                        const uint32_t *__restrict__ retrySlots, float *__restrict__ hitT,
+                                                        uint32_t *__restrict__ hitTri, WorkCounters *__restrict__ wc) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t n = *retryCount;
+    if (n != 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wc->retraced, (unsigned long long)n);
+    uint32_t cNode = 0, cTri = 0, cHit = 0;
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < n) {
+            const uint32_t slot = retrySlots[i];
+            const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
+            const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
+            float t; uint32_t tri;
+            closest_triangle<true, COUNT>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
+            hitT[slot] = t;
+            hitTri[slot] = tri;
+            if (COUNT && tri != REF_NONE) cHit++;
+        }
+    }
+    if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
+}
+
 // shade: one thread per ray of the current queue; finished paths write their sample,
 // continuing paths are compacted into the next queue.
 __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F, const int bounce, const uint32_t loopNum,
@@ -609,21 +825,6 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
     sum[i] += c;
 }
 
-// Closest triangle for caller-supplied rays (rt_trace_rays).
-template <bool CULL>
-__global__ __launch_bounds__(BLOCK) void k_trace_rays(const SceneD S, const float *__restrict__ org, const float *__restrict__ dir,
-                                                      const long long n, float *__restrict__ tOut, int *__restrict__ idOut) {
-    extern __shared__ uint32_t lds_stack[];
-    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const vec3 o = rtm::mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
-    const vec3 d = rtm::mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    float t; uint32_t tri, a = 0, b = 0;
-    closest_triangle<CULL, false>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, a, b);
-    tOut[i] = (tri == REF_NONE) ? -1.0f : t;
-    idOut[i] = (tri == REF_NONE) ? -1 : (int)tri;
-}
-
 // Device arithmetic exposed for the primitive-parity test: out[0..4] per element =
 // a/b, sqrt(|a|), fma(a,b,a), sin and cos of |b| (taken as 0 outside [0, 2*pi]).
 __global__ void k_selftest(const float *__restrict__ a, const float *__restrict__ b, const long long n, float *__restrict__ out) {
@@ -654,6 +855,9 @@ struct RtContext {
 
     // scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
+    float4 *dANodes = nullptr; uint32_t *dATris = nullptr;     // search index
+    uint32_t *dRetrySlots = nullptr;
+    uint32_t lastRetried = 0;       // rays the last rt_trace_rays call re-traced in reference order
     int64_t nTris = 0, nInterior = 0;
     SceneD scene{};
     bool haveScene = false;
@@ -700,7 +904,8 @@ int fail(RtContext *ctx, int code, const std::string &msg) {
 
 // fill counts of queues 0..B and dequeue heads of queues 0..B-1, NSHARD each, one per 128-byte line
 constexpr int QCTL_COUNTS = (RT_MAX_BOUNCES + 1) * NSHARD * CTL_STRIDE;
-constexpr int QCTL_WORDS = QCTL_COUNTS + RT_MAX_BOUNCES * NSHARD * CTL_STRIDE;
+constexpr int QCTL_HEADS = RT_MAX_BOUNCES * NSHARD * CTL_STRIDE;
+constexpr int QCTL_WORDS = QCTL_COUNTS + QCTL_HEADS + RT_MAX_BOUNCES * CTL_STRIDE;  // + one retry count per bounce
 
 hipEvent_t take_event(RtContext *ctx) {
     if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
@@ -823,6 +1028,7 @@ int rt_default_options(RtOptions *out) {
     out->pipeline = RT_PIPELINE_WAVEFRONT;
     out->cull = 1;
     out->count_work = 0;
+    out->accel = 1;
     return RT_OK;
 }
 
@@ -855,6 +1061,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
     if (e == hipSuccess) e = hipMalloc(&ctx->dPathMem, 2 * 11 * P * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&ctx->dHitT, P * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&ctx->dHitTri, P * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->dRetrySlots, P * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->dQueueCtl, QCTL_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->dCounters, sizeof(WorkCounters));
     if (e != hipSuccess) {
@@ -890,6 +1097,7 @@ void rt_destroy(RtContext *ctx) {
     for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->freeEvents) hipEventDestroy(e);
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
+    hipFree(ctx->dANodes); hipFree(ctx->dATris); hipFree(ctx->dRetrySlots);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
     hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
@@ -918,10 +1126,22 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     std::vector<float4> hNodes, hTris, hMats; SceneD S;
     int rc = build_device_scene(ctx, tris, n, nodes, m, hNodes, hTris, hMats, S);
     if (rc != RT_OK) return rc;
+    // search index for the extend stage (skipped when RT_AMD_NO_ACCEL is set or the tree is too deep)
+    rt::Accel accel;
+    bool haveAccel = false;
+    if (!getenv("RT_AMD_NO_ACCEL")) {
+        const float maxAbs = S.cullEps * 1024.0f;
+        if (rt::build_accel(tris, n, maxAbs, accel) == RT_OK && accel.maxDepth <= 56) {
+            haveAccel = true;
+            if (getenv("RT_AMD_VERBOSE"))
+                fprintf(stderr, "rt_amd: search index: %zu nodes, depth %d; reference tree height %d\n", accel.nodes.size(), accel.maxDepth, S.stackEntries - 1);
+            S.stackEntries = std::max(S.stackEntries, accel.maxDepth + 1);
+        }
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
-    ctx->dNodes = ctx->dTris = ctx->dMats = nullptr; ctx->haveScene = false;
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dATris);
+    ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dANodes = nullptr; ctx->dATris = nullptr; ctx->haveScene = false;
     const size_t nodeBytes = std::max<size_t>(hNodes.size(), 4) * sizeof(float4);
     HIP_TRY(ctx, hipMalloc(&ctx->dNodes, nodeBytes));
     HIP_TRY(ctx, hipMalloc(&ctx->dTris, hTris.size() * sizeof(float4)));
@@ -930,6 +1150,17 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     HIP_TRY(ctx, hipMemcpy(ctx->dTris, hTris.data(), hTris.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMats, hMats.data(), hMats.size() * sizeof(float4), hipMemcpyHostToDevice));
     S.nodes = ctx->dNodes; S.tris = ctx->dTris; S.mats = ctx->dMats;
+    S.anodes = nullptr; S.atris = nullptr; S.arootRef = REF_NONE;
+    if (haveAccel) {
+        const size_t ab = std::max<size_t>(accel.nodes.size(), 1) * sizeof(rt::AccelNode);
+        HIP_TRY(ctx, hipMalloc(&ctx->dANodes, ab));
+        HIP_TRY(ctx, hipMalloc(&ctx->dATris, accel.triIdx.size() * sizeof(uint32_t)));
+        if (!accel.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->dANodes, accel.nodes.data(), accel.nodes.size() * sizeof(rt::AccelNode), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->dATris, accel.triIdx.data(), accel.triIdx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        S.anodes = ctx->dANodes; S.atris = ctx->dATris; S.arootRef = accel.rootRef;
+        for (int c = 0; c < 3; c++) { S.arootMin[c] = accel.rootMin[c]; S.arootMax[c] = accel.rootMax[c]; }
+        S.originLimit = 4.0f * (S.cullEps * 1024.0f);
+    }
     ctx->scene = S; ctx->nTris = n; ctx->nInterior = n - 1; ctx->haveScene = true;
     return RT_OK;
 }
@@ -1048,6 +1279,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
     uint32_t *counts = ctx->dQueueCtl, *heads = ctx->dQueueCtl + QCTL_COUNTS;
     const int qstride = NSHARD * CTL_STRIDE;
+    const bool useAccel = ctx->opt.accel != 0 && S.anodes != nullptr;
     for (int f = 0; f < count; f++) {
         const int loopNum = first_loopnum + f;
         HIP_TRY(ctx, hipMemsetAsync(ctx->dQueueCtl, 0, QCTL_WORDS * sizeof(uint32_t), st));
@@ -1057,10 +1289,21 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, st));
+            if (useAccel) {
+                uint32_t *retry = ctx->dQueueCtl + QCTL_COUNTS + QCTL_HEADS + b * CTL_STRIDE;
+                if (cnt) {
+                    hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
+                    hipLaunchKernelGGL((k_extend_retry<true>), dim3(ctx->numCU), dim3(BLOCK), lds, st, S, qin, retry, ctx->dRetrySlots, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
+                } else {
+                    hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
+                    hipLaunchKernelGGL((k_extend_retry<false>), dim3(ctx->numCU), dim3(BLOCK), lds, st, S, qin, retry, ctx->dRetrySlots, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
+                }
+            } else {
 #define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters)
-            if (cull) { if (cnt) LAUNCH_EXT(true, true); else LAUNCH_EXT(true, false); }
-            else { if (cnt) LAUNCH_EXT(false, true); else LAUNCH_EXT(false, false); }
+                if (cull) { if (cnt) LAUNCH_EXT(true, true); else LAUNCH_EXT(true, false); }
+                else { if (cnt) LAUNCH_EXT(false, true); else LAUNCH_EXT(false, false); }
 #undef LAUNCH_EXT
+            }
             HIP_TRY(ctx, hipEventRecord(e1, st));
             ctx->pendingEvents.emplace_back(e0, e1);
             hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, qin, cap, counts + b * qstride,
@@ -1112,6 +1355,7 @@ int rt_get_stats(RtContext *ctx, RtStats *out) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out->rays = wc.rays; out->node_tests = wc.node_tests; out->tri_tests = wc.tri_tests; out->tri_hits = wc.tri_hits;
     out->frames = ctx->frames;
+    out->retraced = wc.retraced;
     return RT_OK;
 }
 
@@ -1128,26 +1372,58 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
     if (!ctx || !origins || !dirs || !t_out || !id_out || n < 0) return fail(ctx, RT_E_INVALID, "rt_trace_rays: bad argument");
     if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_trace_rays: no scene uploaded");
     if (n == 0) return RT_OK;
-    if (n > (int64_t)1 << 28) return fail(ctx, RT_E_INVALID, "rt_trace_rays: more than 2^28 rays per call");
+    if (n > (int64_t)1 << 26) return fail(ctx, RT_E_INVALID, "rt_trace_rays: more than 2^26 rays per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float *dO = nullptr, *dD = nullptr, *dT = nullptr; int *dI = nullptr;
-    hipError_t e = hipMalloc(&dO, (size_t)n * 12);
-    if (e == hipSuccess) e = hipMalloc(&dD, (size_t)n * 12);
-    if (e == hipSuccess) e = hipMalloc(&dT, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc(&dI, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMemcpy(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dD, dirs, (size_t)n * 12, hipMemcpyHostToDevice);
+    // The rays go through the production extend kernels: one queue whose shard 0 holds them all.
+    const uint32_t cap = (uint32_t)((n + 63) / 64 * 64);
+    std::vector<float> soa((size_t)cap * 6, 0.0f);
+    for (int64_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            soa[(size_t)c * cap + i] = origins[3 * i + c];
+            soa[(size_t)(3 + c) * cap + i] = dirs[3 * i + c];
+        }
+    float *dRays = nullptr, *dT = nullptr; uint32_t *dI = nullptr, *dCtl = nullptr, *dRetry = nullptr;
+    std::vector<uint32_t> ctl(QCTL_WORDS, 0u);
+    ctl[0] = (uint32_t)n;
+    std::vector<float> hT((size_t)n); std::vector<uint32_t> hI((size_t)n);
+    hipError_t e = hipMalloc(&dRays, soa.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&dT, (size_t)cap * 4);
+    if (e == hipSuccess) e = hipMalloc(&dI, (size_t)cap * 4);
+    if (e == hipSuccess) e = hipMalloc(&dRetry, (size_t)cap * 4);
+    if (e == hipSuccess) e = hipMalloc(&dCtl, QCTL_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(dRays, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dCtl, ctl.data(), QCTL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        const int blocks = (int)((n + BLOCK - 1) / BLOCK);
-        if (ctx->opt.cull) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(BLOCK), stack_bytes(ctx), ctx->stream, ctx->scene, dO, dD, (long long)n, dT, dI);
-        else hipLaunchKernelGGL(k_trace_rays<false>, dim3(blocks), dim3(BLOCK), stack_bytes(ctx), ctx->stream, ctx->scene, dO, dD, (long long)n, dT, dI);
+        PathSoA q{};
+        q.ox = dRays; q.oy = dRays + cap; q.oz = dRays + 2 * (size_t)cap;
+        q.dx = dRays + 3 * (size_t)cap; q.dy = dRays + 4 * (size_t)cap; q.dz = dRays + 5 * (size_t)cap;
+        const SceneD &S = ctx->scene;
+        const size_t lds = stack_bytes(ctx);
+        const int blocks = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)ctx->numCU * ctx->extendBlocksPerCU);
+        uint32_t *counts = dCtl, *heads = dCtl + QCTL_COUNTS, *retry = dCtl + QCTL_COUNTS + QCTL_HEADS;
+        if (ctx->opt.accel != 0 && S.anodes != nullptr) {
+            hipLaunchKernelGGL((k_extend_fast<false>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, S, q, cap, counts, heads, dT, dI, retry, dRetry, ctx->dCounters);
+            hipLaunchKernelGGL((k_extend_retry<false>), dim3(ctx->numCU), dim3(BLOCK), lds, ctx->stream, S, q, retry, dRetry, dT, dI, ctx->dCounters);
+        } else if (ctx->opt.cull) {
+            hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, S, q, cap, counts, heads, dT, dI, ctx->dCounters);
+        } else {
+            hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, S, q, cap, counts, heads, dT, dI, ctx->dCounters);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(t_out, dT, (size_t)n * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(id_out, dI, (size_t)n * 4, hipMemcpyDeviceToHost);
-    hipFree(dO); hipFree(dD); hipFree(dT); hipFree(dI);
+    if (e == hipSuccess) e = hipMemcpy(hT.data(), dT, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hI.data(), dI, (size_t)n * 4, hipMemcpyDeviceToHost);
+    uint32_t retried = 0;
+    if (e == hipSuccess) e = hipMemcpy(&retried, dCtl + QCTL_COUNTS + QCTL_HEADS, 4, hipMemcpyDeviceToHost);
+    hipFree(dRays); hipFree(dT); hipFree(dI); hipFree(dRetry); hipFree(dCtl);
     if (e != hipSuccess) return fail(ctx, RT_E_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+    for (int64_t i = 0; i < n; i++) {
+        const bool hit = hI[(size_t)i] != REF_NONE;
+        t_out[i] = hit ? hT[(size_t)i] : -1.0f;
+        id_out[i] = hit ? (int32_t)hI[(size_t)i] : -1;
+    }
+    ctx->lastRetried = retried;
     return RT_OK;
 }
 

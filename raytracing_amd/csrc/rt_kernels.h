@@ -44,6 +44,13 @@ struct SceneD {
     float cullEps;          // 2^-10 * largest |coordinate| of the root box
     int32_t stackEntries;   // LDS stack slots per lane (tree height)
     int32_t refill;         // idle lanes of a wave that trigger a fetch of new rays
+    // search index (rt_accel.cpp); anodes == nullptr when absent
+    const float4 *anodes;   // 4 x float4 per node: both children's grown boxes + refs
+    const uint32_t *atris;  // triangle numbers in leaf order
+    uint32_t arootRef;
+    float arootMin[3];
+    float arootMax[3];
+    float originLimit;      // rays starting farther than this from the origin skip the index
 };
 
 struct FrameD {
@@ -64,7 +71,7 @@ struct PathSoA {
 };
 
 struct WorkCounters {       // device-side twin of RtStats
-    unsigned long long rays, node_tests, tri_tests, tri_hits;
+    unsigned long long rays, node_tests, tri_tests, tri_hits, retraced;
 };
 
 }  // namespace rtd

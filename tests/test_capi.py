@@ -38,8 +38,8 @@ int main(void) { printf("%zu %zu %zu %zu %zu %zu\n", sizeof(RtTriangle), sizeof(
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                                os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    assert [int(x) for x in out] == [144, 36, 40, 72, 40, 16]
-    assert C.sizeof(rt.RtStats) == 40 and C.sizeof(rt.RtOptions) == 16
+    assert [int(x) for x in out] == [144, 36, 40, 72, 48, 20]
+    assert C.sizeof(rt.RtStats) == 48 and C.sizeof(rt.RtOptions) == 20
 
 
 def test_no_oracle_in_the_product():
@@ -68,7 +68,7 @@ def test_host_side_argument_checks():
     assert rt.lib.rt_version().startswith(b"rt_amd")
     o = rt.RtOptions()
     assert rt.lib.rt_default_options(C.byref(o)) == 0
-    assert (o.max_bounces, o.pipeline, o.cull, o.count_work) == (4, 0, 1, 0)
+    assert (o.max_bounces, o.pipeline, o.cull, o.count_work, o.accel) == (4, 0, 1, 0, 1)
 
 
 def test_create_without_gpu_fails_loudly():

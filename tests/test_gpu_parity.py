@@ -51,13 +51,16 @@ def test_device_arithmetic_matches_host():
         assert abs(float(out[i, 3]) - np.sin(float(th[i]))) < 3e-7 and abs(float(out[i, 4]) - np.cos(float(th[i]))) < 3e-7
 
 
-@pytest.mark.parametrize("cull", [False, True])
-def test_trace_rays_demo(cull):
+MODES = [dict(accel=False, cull=False), dict(accel=False, cull=True), dict(accel=True, cull=True)]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_trace_rays_demo(mode):
     sc = scenes.demo()
     tris, nodes = rt.bvh_build(sc.triangles())
     r = rt.Renderer(8, 8)
     r.upload(tris, nodes)
-    r.set_options(cull=cull)
+    r.set_options(**mode)
     osc = _oracle_for(tris, nodes, 8, 8, None)
     o, d = scenes.random_rays(20000, 7, extent=9.0)
     o[:, 1] = np.abs(o[:, 1])
@@ -74,18 +77,19 @@ def test_trace_rays_random_scenes(n, snap):
     osc = _oracle_for(tris, nodes, 8, 8, None)
     o, d = scenes.random_rays(6000, n)
     to, io = osc.hit_bvh(o, d)
-    for cull in (False, True):
+    for mode in MODES:
         r = rt.Renderer(8, 8)
         r.upload(tris, nodes)
-        r.set_options(cull=cull)
+        r.set_options(**mode)
         t, ids = r.trace_rays(o, d)
-        assert np.array_equal(ids, io), (n, snap, cull)
-        assert np.array_equal(t, to), (n, snap, cull)
+        assert np.array_equal(ids, io), (n, snap, mode)
+        assert np.array_equal(t, to), (n, snap, mode)
 
 
-@pytest.mark.parametrize("pipeline", [rt.PIPELINE_MEGAKERNEL, rt.PIPELINE_WAVEFRONT])
-@pytest.mark.parametrize("cull", [False, True])
-def test_demo_one_spp_and_running_mean(pipeline, cull):
+@pytest.mark.parametrize("pipeline,cull,accel", [(rt.PIPELINE_MEGAKERNEL, False, False), (rt.PIPELINE_MEGAKERNEL, True, False),
+                                                 (rt.PIPELINE_WAVEFRONT, False, False), (rt.PIPELINE_WAVEFRONT, True, False),
+                                                 (rt.PIPELINE_WAVEFRONT, True, True)])
+def test_demo_one_spp_and_running_mean(pipeline, cull, accel):
     W, H = 200, 120
     sc = scenes.demo()
     tris, nodes = rt.bvh_build(sc.triangles())
@@ -96,7 +100,7 @@ def test_demo_one_spp_and_running_mean(pipeline, cull):
     r.upload(tris, nodes)
     r.set_spheres(sc.spheres())
     r.set_camera(cam)
-    r.set_options(pipeline=pipeline, cull=cull, count_work=True)
+    r.set_options(pipeline=pipeline, cull=cull, count_work=True, accel=accel)
     # 1 spp
     r.render(1, ro[:1])
     got = r.read_mean()
@@ -106,7 +110,9 @@ def test_demo_one_spp_and_running_mean(pipeline, cull):
     s = r.stats()
     assert s["rays"] == st["rays"]
     assert s["tri_hits"] == st["triHits"]
-    if not cull:
+    if accel:
+        assert s["retraced"] < 0.01 * s["rays"]
+    elif not cull:
         assert s["node_tests"] == st["nodeTests"]
         assert s["tri_tests"] == st["triTests"]
     else:

@@ -45,7 +45,7 @@ def main():
     ms, n = r.kernel_time()
     print(f"frames {a.frames} rays {st['rays']} wall {dt * 1e3:.2f} ms -> {st['rays'] / dt / 1e6:.1f} Mrays/s; "
           f"dominant kernel {ms:.2f} ms over {n} launches; nodes/ray {st['node_tests'] / max(st['rays'], 1):.1f} "
-          f"tris/ray {st['tri_tests'] / max(st['rays'], 1):.2f}")
+          f"tris/ray {st['tri_tests'] / max(st['rays'], 1):.2f} retraced {st['retraced']}")
 
 
 if __name__ == "__main__":
