@@ -725,9 +725,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
             if (!more) break;
             continue;
         }
+        // Triangle tests are long and only a few lanes are at a leaf at any time: lanes wait at
+        // their leaf until S.leafBatch of them have gathered (or nobody can take a node step).
+        const unsigned long long mI = __ballot(have && tv.at_interior());
+        const unsigned long long mL = __ballot(have && tv.at_leaf());
+        const bool doLeaves = (mI == 0ull) || ((int)__popcll(mL) >= S.leafBatch);
         if (have) {
             if (tv.at_interior()) tv.node_step(S, stack, BLOCK, cNode);
-            else if (tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
+            else if (doLeaves && tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
             if (tv.done()) {
                 bool exact = tv.tie || !tv.usable(S);
                 if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
@@ -1000,6 +1005,8 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
     S.cullEps = maxAbs * (1.0f / 1024.0f);
     S.stackEntries = maxDepth + 1;
     S.refill = 16;
+    S.leafBatch = 4;
+    if (const char *env = getenv("RT_AMD_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) S.leafBatch = v; }
     if (const char *env = getenv("RT_AMD_REFILL")) { const int v = atoi(env); if (v >= 1 && v <= 64) S.refill = v; }
     return RT_OK;
 }

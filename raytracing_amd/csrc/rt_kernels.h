@@ -44,6 +44,7 @@ struct SceneD {
     float cullEps;          // 2^-10 * largest |coordinate| of the root box
     int32_t stackEntries;   // LDS stack slots per lane (tree height)
     int32_t refill;         // idle lanes of a wave that trigger a fetch of new rays
+    int32_t leafBatch;      // lanes waiting at a leaf that make the wave run the triangle tests
     // search index (rt_accel.cpp); anodes == nullptr when absent
     const float4 *anodes;   // 4 x float4 per node: both children's grown boxes + refs
     const uint32_t *atris;  // triangle numbers in leaf order

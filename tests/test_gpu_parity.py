@@ -124,3 +124,227 @@ def test_demo_one_spp_and_running_mean(pipeline, cull, accel):
     assert np.array_equal(got, want)
     ssum = r.read_sum() / np.float32(len(ro))
     assert np.sqrt(np.mean((ssum - want) ** 2)) < 1e-5
+
+
+def test_golden_vectors(golden_dir):
+    """Committed expected values (made by the oracle from the reference's scene files)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "demo_96x64.npz"))
+    tris = g["tris"].view(rt.TRIANGLE_DTYPE)
+    nodes = g["nodes"].view(rt.NODE_DTYPE)
+    sc = scenes.demo()
+    cam = rt.camera_default(96, 64)
+    for pipeline, accel in ((rt.PIPELINE_WAVEFRONT, True), (rt.PIPELINE_WAVEFRONT, False), (rt.PIPELINE_MEGAKERNEL, False)):
+        r = rt.Renderer(96, 64)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        r.set_options(pipeline=pipeline, accel=accel)
+        r.render(1, g["rand_origin"][:1])
+        assert np.array_equal(r.read_mean(), g["frame1"])
+        r.render(2, g["rand_origin"][1:])
+        assert np.array_equal(r.read_mean(), g["mean4"])
+        t, ids = r.trace_rays(g["ray_o"], g["ray_d"])
+        assert np.array_equal(t, g["ray_t"]) and np.array_equal(ids, g["ray_tri"])
+        r.close()
+
+
+def test_upload_from_reference_textures_matches_struct_upload():
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    tt, tw, tb, bw = rt.pack_textures(tris, nodes)
+    cam = rt.camera_default(64, 48)
+    ro = rt.rand_origins(3, 2)
+    imgs = []
+    for via_tex in (False, True):
+        r = rt.Renderer(64, 48)
+        if via_tex:
+            r.upload_textures(tt, tris.shape[0], tb, nodes.shape[0])
+        else:
+            r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        r.render(1, ro)
+        imgs.append(r.read_mean())
+    assert np.array_equal(imgs[0], imgs[1])
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (7, 5), (8, 8), (9, 17), (130, 70)])
+def test_image_sizes_not_multiple_of_tile(W, H):
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(11, 3)
+    want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro)
+    for pipeline in (rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        r.set_options(pipeline=pipeline)
+        r.render(1, ro)
+        assert np.array_equal(r.read_mean(), want), (W, H, pipeline)
+
+
+@pytest.mark.parametrize("nspheres", [0, 1, 10])
+@pytest.mark.parametrize("bounces", [1, 4, 8])
+def test_spheres_and_bounce_limits(nspheres, bounces):
+    """0, 1 and the maximum of 10 spheres with all three sphere materials; 1, 4 and 8 bounces
+    (8 uses all 16 Sobol dimensions)."""
+    W, H = 96, 64
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    rng = np.random.default_rng(nspheres)
+    sph = np.zeros(nspheres, dtype=rt.SPHERE_DTYPE)
+    for i in range(nspheres):
+        sph[i]["center"] = rng.uniform([-8, 0.5, -4], [4, 8, 3])
+        sph[i]["radius"] = rng.uniform(0.4, 1.3)
+        sph[i]["albedo"] = rng.uniform(0.2, 0.9, size=3)
+        sph[i]["specularRate"] = [0.0, 1.0, 0.3][i % 3]
+        sph[i]["refractionRate"] = [0.0, 1.0, 0.6][(i + 1) % 3]
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(17, 2)
+    want, _ = _oracle_for(tris, nodes, W, H, sph, max_bounces=bounces).render(cam, 1, ro)
+    for pipeline in (rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sph)
+        r.set_camera(cam)
+        r.set_options(max_bounces=bounces, pipeline=pipeline)
+        r.render(1, ro)
+        got = r.read_mean()
+        assert _pass_rate(got, want) >= 0.999
+        assert np.array_equal(got, want), (nspheres, bounces, pipeline, (got == want).all(axis=2).mean())
+
+
+def test_mixed_material_scene_and_arbitrary_camera():
+    """Random triangles with diffuse / mirror / glass / mixed thresholds and lights, camera from
+    angles (not axis aligned), NaN and miss paths included."""
+    W, H = 120, 80
+    tris0 = scenes.random_triangles(400, 77, extent=5.0, size=1.5)
+    tris, nodes = rt.bvh_build(tris0)
+    cam = rt.camera_from_angles((0.5, 0.3, 9.0), -95.0, -3.0, 40.0, W, H)
+    ro = rt.rand_origins(5, 3)
+    sph = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+    sph[0]["center"] = (0, 0, 2); sph[0]["radius"] = 1.0; sph[0]["albedo"] = (0.8, 0.8, 0.8); sph[0]["specularRate"] = 0.5; sph[0]["refractionRate"] = 0.8
+    want, st = _oracle_for(tris, nodes, W, H, sph).render(cam, 1, ro, want_stats=True)
+    for pipeline, accel in ((rt.PIPELINE_WAVEFRONT, True), (rt.PIPELINE_WAVEFRONT, False), (rt.PIPELINE_MEGAKERNEL, False)):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sph)
+        r.set_camera(cam)
+        r.set_options(pipeline=pipeline, accel=accel)
+        r.render(1, ro)
+        got = r.read_mean()
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        m = ~np.isnan(want)
+        assert np.array_equal(got[m], want[m]), (pipeline, accel)
+        assert r.stats()["rays"] == st["rays"]
+
+
+def test_search_index_fallbacks():
+    """Rays the index must hand to the exact path: axis-parallel directions (1/d infinite), NaN
+    directions, origins far outside the scene, and exact ties between coincident triangles."""
+    tris0 = scenes.random_triangles(300, 5, snap=0.5)
+    tris0 = np.concatenate([tris0, tris0[:40]])            # 40 duplicated triangles: exact ties
+    tris, nodes = rt.bvh_build(tris0)
+    osc = _oracle_for(tris, nodes, 8, 8, None)
+    o, d = scenes.random_rays(4000, 9, axis_aligned_fraction=0.25)
+    d[1000:1010] = np.nan
+    o[1100:1200] *= 100.0
+    o[1200:1300] = 0.0                                      # many rays from one point
+    to, io = osc.hit_bvh(o, d)
+    r = rt.Renderer(8, 8)
+    r.upload(tris, nodes)
+    r.set_options(accel=True)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, io) and np.array_equal(t, to)
+    assert (io >= 0).mean() > 0.15
+
+
+def test_synthetic_mesh_parity_and_work_counters():
+    """5k-triangle displaced icosphere in the room (the benchmark scene at low subdivision)."""
+    W, H = 160, 90
+    sc = rt.Scene()
+    sc.push_synthetic(0, 4, 1, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 2)
+    want, st = _oracle_for(tris, nodes, W, H, None).render(cam, 1, ro, want_stats=True)
+    for accel in (True, False):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_camera(cam)
+        r.set_options(accel=accel, cull=False, count_work=True)
+        r.render(1, ro)
+        assert np.array_equal(r.read_mean(), want)
+        s = r.stats()
+        assert s["rays"] == st["rays"] and s["frames"] == 2
+        if accel:
+            assert s["node_tests"] < 0.6 * st["nodeTests"]       # the index tests far fewer boxes
+            assert s["retraced"] <= 0.001 * s["rays"] + 5
+        else:
+            assert s["node_tests"] == st["nodeTests"] and s["tri_tests"] == st["triTests"] and s["tri_hits"] == st["triHits"]
+
+
+def test_full_size_properties_1080p():
+    """At the benchmark resolution the oracle is too slow for every pixel; check properties:
+    both pipelines and both traversal modes give the same image; rendering frames in two calls
+    equals one call; the fp32 sum equals N * mean up to rounding; a band of rows matches the oracle."""
+    W, H = 1920, 1080
+    sc = rt.Scene()
+    sc.push_synthetic(0, 5, 1, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 4)
+    imgs = {}
+    for name, pipeline, accel in (("wf_accel", rt.PIPELINE_WAVEFRONT, True), ("wf_exact", rt.PIPELINE_WAVEFRONT, False),
+                                  ("mega", rt.PIPELINE_MEGAKERNEL, False)):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_camera(cam)
+        r.set_options(pipeline=pipeline, accel=accel)
+        if name == "wf_accel":
+            r.render(1, ro[:1]); r.render(2, ro[1:])
+        else:
+            r.render(1, ro)
+        imgs[name] = r.read_mean()
+        if name == "wf_accel":
+            s = r.read_sum()
+            assert np.allclose(s / 4.0, imgs[name], rtol=1e-6, atol=1e-6)
+        r.close()
+    assert np.array_equal(imgs["wf_accel"], imgs["wf_exact"])
+    assert np.array_equal(imgs["wf_accel"], imgs["mega"])
+    osc = _oracle_for(tris, nodes, W, H, None)
+    hist = np.zeros((H, W, 3), dtype=np.float32)
+    for k in range(4):
+        hist, _, _ = osc.render_frame(cam, k + 1, float(ro[k]), hist, rows=(500, 516))
+    assert np.array_equal(imgs["wf_accel"][500:516], hist[500:516])
+
+
+def test_error_paths():
+    r = rt.Renderer(16, 16)
+    ro = rt.rand_origins(1, 1)
+    with pytest.raises(rt.RtError, match="no scene"):
+        r.render(1, ro)
+    tris, nodes = rt.bvh_build(scenes.demo().triangles())
+    bad = nodes.copy()
+    bad[3]["offsetOrRc"] = 1       # right child pointing backwards
+    with pytest.raises(rt.RtError, match="malformed"):
+        r.upload(tris, bad)
+    with pytest.raises(rt.RtError, match="2n-1"):
+        r.upload(tris, nodes[:-1])
+    r.upload(tris, nodes)
+    with pytest.raises(rt.RtError, match="no camera"):
+        r.render(1, ro)
+    r.set_camera(rt.camera_default(16, 16))
+    with pytest.raises(rt.RtError, match="first_loopnum"):
+        r.render(0, ro)
+    with pytest.raises(rt.RtError):
+        r.set_options(max_bounces=9)
+    with pytest.raises(rt.RtError, match="0..10"):
+        r.set_spheres(np.zeros(11, dtype=rt.SPHERE_DTYPE))
+    r.render(1, ro)
+    assert r.stats()["frames"] == 1
+    r.reset()
+    assert r.stats()["frames"] == 0 and (r.read_sum() == 0).all()
