@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
+    ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,7 +109,7 @@ def main():
     r.upload(tris, nodes)
     r.set_spheres(sc.spheres())
     r.set_camera(cam)
-    r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False)
+    r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False, accel=not args.no_accel)
     sum_t = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     r.bind_sum_buffer(sum_t.data_ptr())
 
@@ -159,7 +160,7 @@ def main():
         mean_img = (sum_t / float(K * world * F)).cpu().numpy()
         value = rays_total / elapsed / 1e6
         # instrumented re-run of this rank's timed frames: identical traversal, counts the work
-        r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=True)
+        r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=True, accel=not args.no_accel)
         r.reset()
         ksteps = min(K, 2)
         for s in range(ksteps):
@@ -169,7 +170,7 @@ def main():
         bytes_alg = 32.0 * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]
         bytes_per_ray = bytes_alg / max(w["rays"], 1)
         achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        dominant = "k_extend" if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
+        dominant = ("k_extend" if args.no_accel else "k_extend_fast (+k_extend_retry)") if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
         result = {
             "metric": "Mrays/sec (paths x bounces) at 1080p" if H == 1080 else "Mrays/sec (paths x bounces)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -178,7 +179,7 @@ def main():
             "config": {"workload": f"{args.workload}: {desc} (BASELINE.json configs[{cfg_idx}])",
                        "triangles": int(tris.shape[0]), "bvh_nodes": int(nodes.shape[0]),
                        "resolution": f"{W}x{H}", "spp_per_step": F, "max_bounces": bounces,
-                       "pipeline": args.pipeline, "cull": not args.no_cull,
+                       "pipeline": args.pipeline, "cull": not args.no_cull, "search_index": not args.no_accel,
                        "parallelism": f"spp-partition x{world}, one RCCL sum-reduce" if world > 1 else "single GPU",
                        "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
                        "image_mean": float(mean_img.mean())},
