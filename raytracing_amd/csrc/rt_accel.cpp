@@ -29,7 +29,6 @@ namespace rt {
 namespace {
 
 constexpr int NBINS = 16;
-constexpr int LEAF_MAX = 4;
 
 struct Prim {
     float mn[3], mx[3], c[3];
@@ -54,6 +53,7 @@ struct TmpNode {
 };
 
 struct Builder {
+    int leafMax = 1;
     const Prim *prims;
     uint32_t *idx;
     std::vector<TmpNode> nodes;
@@ -102,7 +102,7 @@ struct Builder {
             }
         }
         const float parentArea = box.half_area();
-        if (count <= LEAF_MAX) {
+        if (count <= leafMax) {
             const float leafCost = (float)count;
             const float splitCost = (bestAxis < 0 || !(parentArea > 0.0f)) ? INFINITY : 1.0f + bestCost / parentArea;
             if (leafCost <= splitCost) return leaf_ref(begin, count);
@@ -140,7 +140,7 @@ struct Builder {
 
 }  // namespace
 
-int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, Accel &out) {
+int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMax, Accel &out) {
     out = Accel();
     if (n <= 0 || n >= ((int64_t)1 << 28)) return RT_E_INVALID;
     std::vector<Prim> prims((size_t)n);
@@ -167,6 +167,7 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, Accel &out
     out.triIdx.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) out.triIdx[(size_t)i] = (uint32_t)i;
     Builder b;
+    b.leafMax = std::min(std::max(leafMax, 1), 8);
     b.prims = prims.data(); b.idx = out.triIdx.data();
     b.nodes.resize((size_t)std::max<int64_t>(n - 1, 1));
     Box rootBox;
@@ -176,7 +177,8 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, Accel &out
     // Relayout in depth-first order (a left child follows its parent) and measure the depth.
     out.nodes.resize(used);
     out.maxDepth = 0;
-    if (root & ACCEL_LEAF_BIT) { out.rootRef = root; return RT_OK; }
+    out.directLeaves = (b.leafMax == 1);
+    if (root & ACCEL_LEAF_BIT) { out.rootRef = out.directLeaves ? (ACCEL_LEAF_BIT | out.triIdx[root & 0x0FFFFFFFu]) : root; return RT_OK; }
     struct Item { uint32_t old; uint32_t parentNew; int side; int depth; };
     std::vector<Item> stack;
     stack.push_back({root, 0xFFFFFFFFu, 0, 1});
@@ -191,6 +193,10 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, Accel &out
             dst.rmin[k] = src.rbox.mn[k]; dst.rmax[k] = src.rbox.mx[k];
         }
         dst.left = src.left; dst.right = src.right; dst.pad0 = dst.pad1 = 0;
+        if (b.leafMax == 1) {       // one triangle per leaf: the ref names the triangle itself
+            if (dst.left & ACCEL_LEAF_BIT) dst.left = ACCEL_LEAF_BIT | out.triIdx[dst.left & 0x0FFFFFFFu];
+            if (dst.right & ACCEL_LEAF_BIT) dst.right = ACCEL_LEAF_BIT | out.triIdx[dst.right & 0x0FFFFFFFu];
+        }
         if (it.parentNew != 0xFFFFFFFFu) {
             if (it.side == 0) out.nodes[it.parentNew].left = me; else out.nodes[it.parentNew].right = me;
         }

@@ -7,7 +7,9 @@
 
 namespace rt {
 
-constexpr uint32_t ACCEL_LEAF_BIT = 0x80000000u;    // leaf ref: LEAF | (count-1) << 28 | first index into triIdx
+// leaf ref: LEAF | (count-1) << 28 | first index into triIdx; with directLeaves (one triangle
+// per leaf): LEAF | triangle number
+constexpr uint32_t ACCEL_LEAF_BIT = 0x80000000u;
 
 struct AccelNode {          // 64 bytes: both children's (grown) boxes and their refs
     float lmin[3], lmax[3];
@@ -23,9 +25,10 @@ struct Accel {
     uint32_t rootRef = 0;
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     int maxDepth = 0;               // interior levels; bounds the traversal stack
+    bool directLeaves = false;
 };
 
 // sceneMaxAbs: largest |coordinate| of the scene's bounding box.
-int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, Accel &out);
+int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMax, Accel &out);
 
 }  // namespace rt

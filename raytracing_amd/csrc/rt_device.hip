@@ -260,9 +260,19 @@ template <bool COUNT>
 struct FastTrav {
     vec3 o, d, inv;
     float hitMin, hitCull;
-    uint32_t best, cur;
+    uint32_t best, cur;         // cur: interior node of the index, or REF_NONE when the stack is empty
     int sp;
     bool tie;
+    // Triangles met but not yet tested.  Leaves of the index hold one triangle each and are
+    // named by their parent, so a node step never has to stop at a leaf: it queues the
+    // triangle here and goes on.  The wave tests queued triangles together (one per lane per
+    // pass) when enough lanes have some; testing them one lane at a time costs a full pass of
+    // the long triangle code at a few percent lane utilisation.  The search keeps every
+    // candidate whatever the order of the tests.
+    uint32_t pend0, pend1, pend2, pend3;
+    int npend;
+
+    static constexpr int PEND_MAX = 4;
 
     static __device__ __forceinline__ void box_span(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                                     const vec3 o, const vec3 inv, float &tn, float &tf) {
@@ -275,36 +285,48 @@ struct FastTrav {
     __device__ __forceinline__ bool box_live(float tn, float tf) const {
         return !(tn > tf) && !(tf < 0.0f) && !(tn > hitCull);
     }
-
-    __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
-        o = o_; d = d_;
-        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        hitMin = HIT_MIN_INIT;
-        hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-        best = REF_NONE; tie = false; sp = 0;
-        cur = S.arootRef;
-        float tn, tf;
-        box_span(S.arootMin[0], S.arootMin[1], S.arootMin[2], S.arootMax[0], S.arootMax[1], S.arootMax[2], o, inv, tn, tf);
-        if (COUNT) nNode++;
-        if (!box_live(tn, tf)) cur = REF_NONE;
-        // a ray with a zero, NaN or infinite direction component is not searched here at all
-        // (with NaN every box would count as hit); the caller sends it to the exact path
-        if (!usable(S)) cur = REF_NONE;
-    }
     // rays this search may be used for: finite 1/d and an origin within the range the growth
     // of the index boxes was sized for
     __device__ __forceinline__ bool usable(const SceneD &S) const {
         const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
         return finite3(inv) && (oM <= S.originLimit);
     }
-    __device__ __forceinline__ bool at_interior() const { return (int32_t)cur >= 0; }
-    __device__ __forceinline__ bool at_leaf() const { return (cur & LEAF_BIT) && cur != REF_NONE; }
-    __device__ __forceinline__ bool done() const { return cur == REF_NONE; }
-    __device__ __forceinline__ void pop(const uint32_t *stack, const int stride) {
-        cur = REF_NONE;
-        if (sp > 0) cur = stack[(--sp) * stride];
+    __device__ __forceinline__ void queue_triangle(uint32_t ti) {
+        pend3 = (npend == 3) ? ti : pend3;
+        pend2 = (npend == 2) ? ti : pend2;
+        pend1 = (npend == 1) ? ti : pend1;
+        pend0 = (npend == 0) ? ti : pend0;
+        npend++;
+    }
+    __device__ __forceinline__ uint32_t unqueue_triangle() {
+        npend--;
+        return (npend == 0) ? pend0 : ((npend == 1) ? pend1 : ((npend == 2) ? pend2 : pend3));
     }
 
+    __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
+        o = o_; d = d_;
+        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        hitMin = HIT_MIN_INIT;
+        hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+        best = REF_NONE; tie = false; sp = 0; npend = 0;
+        pend0 = pend1 = pend2 = pend3 = 0u;
+        float tn, tf;
+        box_span(S.arootMin[0], S.arootMin[1], S.arootMin[2], S.arootMax[0], S.arootMax[1], S.arootMax[2], o, inv, tn, tf);
+        if (COUNT) nNode++;
+        cur = REF_NONE;
+        // a ray with a zero, NaN or infinite direction component is not searched here at all
+        // (with NaN every box would count as hit); the caller sends it to the exact path
+        if (box_live(tn, tf) && usable(S)) {
+            if (S.arootRef & LEAF_BIT) queue_triangle(S.arootRef & ~LEAF_BIT);     // one-triangle scene
+            else cur = S.arootRef;
+        }
+    }
+    __device__ __forceinline__ bool can_step() const { return cur != REF_NONE && npend <= PEND_MAX - 2; }
+    __device__ __forceinline__ bool wants_test() const { return npend > 0 && (cur == REF_NONE || npend > PEND_MAX - 2); }
+    __device__ __forceinline__ bool finished() const { return cur == REF_NONE && npend == 0; }
+
+    // cur is an interior node: test both children; leaf children are queued, interior children
+    // are entered nearest first (the other one is deferred on the stack)
     __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t &nNode) {
         const float4 *rec = S.anodes + (size_t)cur * 4;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
@@ -312,8 +334,10 @@ struct FastTrav {
         box_span(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tnL, tfL);
         box_span(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tnR, tfR);
         if (COUNT) nNode += 2;
-        const bool hitL = box_live(tnL, tfL), hitR = box_live(tnR, tfR);
         const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+        bool hitL = box_live(tnL, tfL), hitR = box_live(tnR, tfR);
+        if (hitL && (left & LEAF_BIT)) { queue_triangle(left & ~LEAF_BIT); hitL = false; }
+        if (hitR && (right & LEAF_BIT)) { queue_triangle(right & ~LEAF_BIT); hitR = false; }
         if (hitL && hitR) {
             const bool leftFirst = !(tnR < tnL);
             cur = leftFirst ? left : right;
@@ -323,28 +347,26 @@ struct FastTrav {
         } else if (hitR) {
             cur = right;
         } else {
-            pop(stack, stride);
+            cur = REF_NONE;
+            if (sp > 0) cur = stack[(--sp) * stride];
         }
     }
 
-    __device__ __forceinline__ void leaf_step(const SceneD &S, const uint32_t *stack, const int stride, uint32_t &nTri) {
-        const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-            const uint32_t ti = S.atris[first + k];
-            const float4 *rec = S.tris + (size_t)ti * 4;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            const float dis = triangle_test(q0, q1, q2, q3, o, d);
-            if (COUNT) nTri++;
-            if (dis > 0.0f) {
-                if (dis < hitMin) {
-                    hitMin = dis; best = ti; tie = false;
-                    hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-                } else if (dis == hitMin && ti != best) {
-                    tie = true;
-                }
+    // tests one queued triangle with the reference's hitTriangle arithmetic
+    __device__ __forceinline__ void test_step(const SceneD &S, uint32_t &nTri) {
+        const uint32_t ti = unqueue_triangle();
+        const float4 *rec = S.tris + (size_t)ti * 4;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        const float dis = triangle_test(q0, q1, q2, q3, o, d);
+        if (COUNT) nTri++;
+        if (dis > 0.0f) {
+            if (dis < hitMin) {
+                hitMin = dis; best = ti; tie = false;
+                hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
+            } else if (dis == hitMin && ti != best) {
+                tie = true;
             }
         }
-        pop(stack, stride);
     }
 };
 
@@ -675,10 +697,16 @@ __global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA 
     if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
 }
 
-// extend through the search index: same refill loop as k_extend, FastTrav instead of the
-// reference-order traversal.  A finished ray whose result cannot be proven equal to the
-// reference's (tie, non-finite 1/d, origin far outside the scene, or the reference not reaching
-// the triangle) is appended to the retry list and re-traced by k_extend_retry.
+// extend through the search index.  Persistent waves; each lane owns one ray at a time and is
+// in one of three conditions: it can take a node step, it is waiting for a triangle pass
+// (its queue is full, or its traversal is over but triangles are still queued), or it is
+// finished.  Per iteration the wave runs at most one of each of three code blocks, each only
+// when enough lanes need it: node steps (every iteration), a triangle pass (when S.leafBatch
+// lanes wait for one or nobody can step), and the finish + refill block (when S.refill lanes
+// are finished: their results are written, then they start on new rays from the queue).
+// A finished ray whose result cannot be proven equal to the reference's (tie, unusable ray, or
+// the reference not reaching the triangle) is appended to the retry list and re-traced by
+// k_extend_retry.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const PathSoA Q, const uint32_t cap,
                                                        const uint32_t *__restrict__ qcount, uint32_t *__restrict__ qhead,
@@ -692,48 +720,20 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t cNode = 0, cTri = 0, cHit = 0;
     FastTrav<COUNT> tv;
-    tv.cur = REF_NONE;
-    bool have = false;
+    tv.cur = REF_NONE; tv.npend = 0;
+    bool have = false;                                  // this lane owns a ray (possibly finished, not yet written)
     uint32_t slot = 0;
     uint32_t k = 0, shard = wave % NSHARD;
     uint32_t n = qcount[shard * CTL_STRIDE];
-    bool more = true;
+    bool more = true;                                   // wave-uniform: some shard may still hold rays
     while (true) {
-        const unsigned long long idle = __ballot(!have);
-        const uint32_t nIdle = (uint32_t)__popcll(idle);
-        if (more && (nIdle >= (uint32_t)S.refill)) {
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)idle) - 1;
-            if ((int)lane == leader) base = atomicAdd(qhead + shard * CTL_STRIDE, nIdle);
-            base = __shfl(base, leader);
-            if (base >= n) {
-                k++;
-                if (k == NSHARD) more = false;
-                else { shard = (wave + k) % NSHARD; n = qcount[shard * CTL_STRIDE]; }
-                continue;
-            }
-            const uint32_t idx = base + (uint32_t)__popcll(idle & below);
-            if (!have && idx < n) {
-                slot = shard * cap + idx;
-                const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
-                const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
-                tv.begin(S, o, d, cNode);
-                have = true;
-            }
-        }
-        if (__ballot(have) == 0ull) {
-            if (!more) break;
-            continue;
-        }
-        // Triangle tests are long and only a few lanes are at a leaf at any time: lanes wait at
-        // their leaf until S.leafBatch of them have gathered (or nobody can take a node step).
-        const unsigned long long mI = __ballot(have && tv.at_interior());
-        const unsigned long long mL = __ballot(have && tv.at_leaf());
-        const bool doLeaves = (mI == 0ull) || ((int)__popcll(mL) >= S.leafBatch);
-        if (have) {
-            if (tv.at_interior()) tv.node_step(S, stack, BLOCK, cNode);
-            else if (doLeaves && tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
-            if (tv.done()) {
+        // ---- finish + refill
+        const bool fin = have && tv.finished();
+        const unsigned long long freeMask = __ballot(!have || fin);
+        const uint32_t nFree = (uint32_t)__popcll(freeMask);
+        const unsigned long long busyMask = __ballot(have && !fin);
+        if ((more && nFree >= (uint32_t)S.refill) || busyMask == 0ull) {
+            if (fin) {
                 bool exact = tv.tie || !tv.usable(S);
                 if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
                 hitT[slot] = tv.hitMin;
@@ -742,6 +742,37 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
                 else if (COUNT && tv.best != REF_NONE) cHit++;
                 have = false;
             }
+            if (!more) {
+                if (busyMask == 0ull) break;
+            } else {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)freeMask) - 1;
+                if ((int)lane == leader) base = atomicAdd(qhead + shard * CTL_STRIDE, nFree);
+                base = __shfl(base, leader);
+                if (base >= n) {                        // this shard is drained: move on
+                    k++;
+                    if (k == NSHARD) more = false;
+                    else { shard = (wave + k) % NSHARD; n = qcount[shard * CTL_STRIDE]; }
+                    continue;
+                }
+                const uint32_t idx = base + (uint32_t)__popcll(freeMask & below);
+                if (!have && idx < n) {
+                    slot = shard * cap + idx;
+                    const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
+                    const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
+                    tv.begin(S, o, d, cNode);
+                    have = true;
+                }
+            }
+        }
+        // ---- node steps
+        const bool step = have && tv.can_step();
+        if (step) tv.node_step(S, stack, BLOCK, cNode);
+        // ---- triangle pass
+        const unsigned long long waiting = __ballot(have && tv.wants_test());
+        const unsigned long long stepping = __ballot(have && tv.can_step());
+        if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
+            if (have && tv.npend > 0) tv.test_step(S, cTri);
         }
     }
     if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
@@ -1004,8 +1035,8 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
     if (n == 1 && nodes[0].offsetOrRc != 0) return fail(ctx, RT_E_INVALID, "scene upload: single leaf must reference triangle 0");
     S.cullEps = maxAbs * (1.0f / 1024.0f);
     S.stackEntries = maxDepth + 1;
-    S.refill = 16;
-    S.leafBatch = 4;
+    S.refill = 32;
+    S.leafBatch = 1;
     if (const char *env = getenv("RT_AMD_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) S.leafBatch = v; }
     if (const char *env = getenv("RT_AMD_REFILL")) { const int v = atoi(env); if (v >= 1 && v <= 64) S.refill = v; }
     return RT_OK;
@@ -1138,7 +1169,9 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     bool haveAccel = false;
     if (!getenv("RT_AMD_NO_ACCEL")) {
         const float maxAbs = S.cullEps * 1024.0f;
-        if (rt::build_accel(tris, n, maxAbs, accel) == RT_OK && accel.maxDepth <= 56) {
+        int leafMax = 1;
+        if (const char *env = getenv("RT_AMD_LEAF_MAX")) leafMax = atoi(env);
+        if (rt::build_accel(tris, n, maxAbs, leafMax, accel) == RT_OK && accel.maxDepth <= 56) {
             haveAccel = true;
             if (getenv("RT_AMD_VERBOSE"))
                 fprintf(stderr, "rt_amd: search index: %zu nodes, depth %d; reference tree height %d\n", accel.nodes.size(), accel.maxDepth, S.stackEntries - 1);
@@ -1162,9 +1195,10 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         const size_t ab = std::max<size_t>(accel.nodes.size(), 1) * sizeof(rt::AccelNode);
         HIP_TRY(ctx, hipMalloc(&ctx->dANodes, ab));
         HIP_TRY(ctx, hipMalloc(&ctx->dATris, accel.triIdx.size() * sizeof(uint32_t)));
+        const bool direct = accel.directLeaves;
         if (!accel.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->dANodes, accel.nodes.data(), accel.nodes.size() * sizeof(rt::AccelNode), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(ctx->dATris, accel.triIdx.data(), accel.triIdx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        S.anodes = ctx->dANodes; S.atris = ctx->dATris; S.arootRef = accel.rootRef;
+        S.anodes = ctx->dANodes; S.atris = direct ? nullptr : ctx->dATris; S.arootRef = accel.rootRef;
         for (int c = 0; c < 3; c++) { S.arootMin[c] = accel.rootMin[c]; S.arootMax[c] = accel.rootMax[c]; }
         S.originLimit = 4.0f * (S.cullEps * 1024.0f);
     }
