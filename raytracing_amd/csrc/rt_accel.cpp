@@ -138,6 +138,75 @@ struct Builder {
     }
 };
 
+
+// Collapses the binary tree into 4-wide nodes: a wide node starts from the two children of a
+// binary node and repeatedly replaces its largest interior child by that child's two children.
+void collapse_wide(const Builder &b, uint32_t root, Accel &out) {
+    struct Child { uint32_t ref; Box box; };
+    struct Item { uint32_t old; uint32_t parent; int slot; int depth; };
+    std::vector<Item> stack;
+    stack.push_back({root, 0xFFFFFFFFu, 0, 1});
+    out.wide.clear();
+    out.wide.reserve(b.nodes.size() / 2 + 1);
+    out.wideDepth = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        const uint32_t me = (uint32_t)out.wide.size();
+        out.wide.emplace_back();
+        if (it.parent != 0xFFFFFFFFu) out.wide[it.parent].ref[it.slot] = me;
+        if (it.depth > out.wideDepth) out.wideDepth = it.depth;
+        Child ch[4]; int n = 2;
+        ch[0] = {b.nodes[it.old].left, b.nodes[it.old].lbox};
+        ch[1] = {b.nodes[it.old].right, b.nodes[it.old].rbox};
+        while (n < 4) {
+            int pick = -1; float area = -1.0f;
+            for (int c = 0; c < n; c++)
+                if (!(ch[c].ref & ACCEL_LEAF_BIT) && ch[c].box.half_area() > area) { area = ch[c].box.half_area(); pick = c; }
+            if (pick < 0) break;
+            const TmpNode &src = b.nodes[ch[pick].ref];
+            ch[pick] = {src.left, src.lbox};
+            ch[n++] = {src.right, src.rbox};
+        }
+        Box nb; nb.reset();
+        for (int c = 0; c < n; c++) nb.grow(ch[c].box);
+        WideNode w;
+        std::memset(&w, 0, sizeof w);
+        w.exps = 0;
+        double scale[3];
+        for (int k = 0; k < 3; k++) {
+            w.origin[k] = nb.mn[k];
+            const double ext = (double)nb.mx[k] - (double)nb.mn[k];
+            int e = (ext > 0.0) ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+            e = std::min(std::max(e, -100), 100);
+            while (255.0 * std::ldexp(1.0, e) < ext) e++;
+            scale[k] = std::ldexp(1.0, e);
+            w.exps |= (uint32_t)(e + 127) << (8 * k);
+        }
+        for (int c = 0; c < 4; c++) {
+            if (c >= n) {
+                w.ref[c] = 0xFFFFFFFFu;
+                for (int k = 0; k < 3; k++) { w.qlo[k] |= 255u << (8 * c); }
+                continue;
+            }
+            for (int k = 0; k < 3; k++) {
+                double lo = std::floor(((double)ch[c].box.mn[k] - (double)nb.mn[k]) / scale[k]);
+                double hi = std::ceil(((double)ch[c].box.mx[k] - (double)nb.mn[k]) / scale[k]);
+                lo = std::min(std::max(lo, 0.0), 255.0); hi = std::min(std::max(hi, 0.0), 255.0);
+                w.qlo[k] |= (uint32_t)lo << (8 * c);
+                w.qhi[k] |= (uint32_t)hi << (8 * c);
+            }
+            if (ch[c].ref & ACCEL_LEAF_BIT) w.ref[c] = ACCEL_LEAF_BIT | out.triIdx[ch[c].ref & 0x0FFFFFFFu];
+            else w.ref[c] = ch[c].ref;      // binary index for now; patched when the child is emitted
+        }
+        out.wide[me] = w;
+        // children are emitted depth first; slot 0's subtree follows its parent
+        for (int c = n - 1; c >= 0; c--)
+            if (!(ch[c].ref & ACCEL_LEAF_BIT)) stack.push_back({ch[c].ref, me, c, it.depth + 1});
+    }
+    out.wideRootRef = 0;
+    out.wideStack = 3 * out.wideDepth + 1;
+}
+
 }  // namespace
 
 int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMax, Accel &out) {
@@ -206,6 +275,7 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMa
         if (!(src.left & ACCEL_LEAF_BIT)) stack.push_back({src.left, me, 0, it.depth + 1});
     }
     out.rootRef = 0;
+    if (out.directLeaves) collapse_wide(b, root, out);
     return RT_OK;
 }
 

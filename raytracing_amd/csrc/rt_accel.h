@@ -19,6 +19,22 @@ struct AccelNode {          // 64 bytes: both children's (grown) boxes and their
 };
 static_assert(sizeof(AccelNode) == 64, "AccelNode layout");
 
+// 4-wide node of the index as the GPU reads it (64 bytes).  The boxes of up to four children are
+// stored as 8-bit offsets from the node's own box corner, on a per-axis power-of-two grid, and
+// are rounded outwards, so the quantised boxes contain the (already grown) child boxes.
+//   decode: lo = origin[k] + qlo * 2^(exp_k - 127), hi = origin[k] + qhi * 2^(exp_k - 127)
+// qlo[k]/qhi[k] hold one byte per child (child c in bits 8c..8c+7); an empty slot has
+// ref == 0xFFFFFFFF and an inverted box (qlo 255, qhi 0).
+struct WideNode {
+    float origin[3];
+    uint32_t exps;          // exp_x | exp_y << 8 | exp_z << 16 (biased float exponents)
+    uint32_t ref[4];        // interior: index into the wide node array; leaf: LEAF | triangle number
+    uint32_t qlo[3];
+    uint32_t qhi[3];
+    uint32_t pad[2];
+};
+static_assert(sizeof(WideNode) == 64, "WideNode layout");
+
 struct Accel {
     std::vector<AccelNode> nodes;
     std::vector<uint32_t> triIdx;   // triangle numbers (uploaded order) in leaf order
@@ -26,6 +42,10 @@ struct Accel {
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     int maxDepth = 0;               // interior levels; bounds the traversal stack
     bool directLeaves = false;
+    std::vector<WideNode> wide;     // 4-wide collapse of `nodes` (only with directLeaves)
+    uint32_t wideRootRef = 0;
+    int wideDepth = 0;              // levels of wide interior nodes
+    int wideStack = 0;              // bound on deferred entries during a traversal
 };
 
 // sceneMaxAbs: largest |coordinate| of the scene's bounding box.

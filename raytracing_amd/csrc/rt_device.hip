@@ -260,28 +260,20 @@ template <bool COUNT>
 struct FastTrav {
     vec3 o, d, inv;
     float hitMin, hitCull;
-    uint32_t best, cur;         // cur: interior node of the index, or REF_NONE when the stack is empty
+    uint32_t best, cur;         // cur: interior node of the index, or REF_NONE when nothing is left
     int sp;
     bool tie;
     // Triangles met but not yet tested.  Leaves of the index hold one triangle each and are
     // named by their parent, so a node step never has to stop at a leaf: it queues the
     // triangle here and goes on.  The wave tests queued triangles together (one per lane per
-    // pass) when enough lanes have some; testing them one lane at a time costs a full pass of
-    // the long triangle code at a few percent lane utilisation.  The search keeps every
-    // candidate whatever the order of the tests.
-    uint32_t pend0, pend1, pend2, pend3;
+    // pass); testing them one lane at a time costs a full pass of the long triangle code at a
+    // few percent lane utilisation.  The search keeps every candidate whatever the order of
+    // the tests.
+    uint32_t pend0, pend1, pend2, pend3, pend4, pend5;
     int npend;
 
-    static constexpr int PEND_MAX = 4;
+    static constexpr int PEND_MAX = 6;      // a node step may queue up to 4 triangles
 
-    static __device__ __forceinline__ void box_span(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                                    const vec3 o, const vec3 inv, float &tn, float &tf) {
-        const float x0 = (mnx - o.x) * inv.x, x1 = (mxx - o.x) * inv.x;
-        const float y0 = (mny - o.y) * inv.y, y1 = (mxy - o.y) * inv.y;
-        const float z0 = (mnz - o.z) * inv.z, z1 = (mxz - o.z) * inv.z;
-        tn = fmaxf(fminf(x0, x1), fmaxf(fminf(y0, y1), fminf(z0, z1)));
-        tf = fminf(fmaxf(x0, x1), fminf(fmaxf(y0, y1), fmaxf(z0, z1)));
-    }
     __device__ __forceinline__ bool box_live(float tn, float tf) const {
         return !(tn > tf) && !(tf < 0.0f) && !(tn > hitCull);
     }
@@ -291,16 +283,30 @@ struct FastTrav {
         const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
         return finite3(inv) && (oM <= S.originLimit);
     }
+    __device__ __forceinline__ float child_entry(float nx_, float ny_, float nz_, float fx_, float fy_, float fz_, uint32_t r) const {
+        const float tn = fmaxf(nx_, fmaxf(ny_, nz_)), tf = fminf(fx_, fminf(fy_, fz_));
+        return (box_live(tn, tf) && r != REF_NONE) ? tn : INFINITY;
+    }
+    // shift-register stack (top in pend0): no dynamic register indexing
     __device__ __forceinline__ void queue_triangle(uint32_t ti) {
-        pend3 = (npend == 3) ? ti : pend3;
-        pend2 = (npend == 2) ? ti : pend2;
-        pend1 = (npend == 1) ? ti : pend1;
-        pend0 = (npend == 0) ? ti : pend0;
+        pend5 = pend4; pend4 = pend3; pend3 = pend2; pend2 = pend1; pend1 = pend0; pend0 = ti;
         npend++;
     }
     __device__ __forceinline__ uint32_t unqueue_triangle() {
+        const uint32_t r = pend0;
+        pend0 = pend1; pend1 = pend2; pend2 = pend3; pend3 = pend4; pend4 = pend5;
         npend--;
-        return (npend == 0) ? pend0 : ((npend == 1) ? pend1 : ((npend == 2) ? pend2 : pend3));
+        return r;
+    }
+    // deferred nodes: LDS column of this lane first, global overflow beyond S.aldsEntries
+    __device__ __forceinline__ void push(const SceneD &S, uint32_t *stack, const int stride, uint32_t *ovf, uint32_t v) {
+        if (sp < S.aldsEntries) stack[sp * stride] = v;
+        else ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride] = v;
+        sp++;
+    }
+    __device__ __forceinline__ uint32_t pop(const SceneD &S, const uint32_t *stack, const int stride, const uint32_t *ovf) {
+        sp--;
+        return (sp < S.aldsEntries) ? stack[sp * stride] : ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride];
     }
 
     __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
@@ -309,9 +315,13 @@ struct FastTrav {
         hitMin = HIT_MIN_INIT;
         hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
         best = REF_NONE; tie = false; sp = 0; npend = 0;
-        pend0 = pend1 = pend2 = pend3 = 0u;
-        float tn, tf;
-        box_span(S.arootMin[0], S.arootMin[1], S.arootMin[2], S.arootMax[0], S.arootMax[1], S.arootMax[2], o, inv, tn, tf);
+        pend0 = pend1 = pend2 = pend3 = pend4 = pend5 = 0u;
+        // root box (not quantised)
+        const float x0 = (S.arootMin[0] - o.x) * inv.x, x1 = (S.arootMax[0] - o.x) * inv.x;
+        const float y0 = (S.arootMin[1] - o.y) * inv.y, y1 = (S.arootMax[1] - o.y) * inv.y;
+        const float z0 = (S.arootMin[2] - o.z) * inv.z, z1 = (S.arootMax[2] - o.z) * inv.z;
+        const float tn = fmaxf(fminf(x0, x1), fmaxf(fminf(y0, y1), fminf(z0, z1)));
+        const float tf = fminf(fmaxf(x0, x1), fminf(fmaxf(y0, y1), fmaxf(z0, z1)));
         if (COUNT) nNode++;
         cur = REF_NONE;
         // a ray with a zero, NaN or infinite direction component is not searched here at all
@@ -321,35 +331,50 @@ struct FastTrav {
             else cur = S.arootRef;
         }
     }
-    __device__ __forceinline__ bool can_step() const { return cur != REF_NONE && npend <= PEND_MAX - 2; }
-    __device__ __forceinline__ bool wants_test() const { return npend > 0 && (cur == REF_NONE || npend > PEND_MAX - 2); }
+    __device__ __forceinline__ bool can_step() const { return cur != REF_NONE && npend <= PEND_MAX - 4; }
+    __device__ __forceinline__ bool wants_test() const { return npend > 0 && (cur == REF_NONE || npend > PEND_MAX - 4); }
     __device__ __forceinline__ bool finished() const { return cur == REF_NONE && npend == 0; }
 
-    // cur is an interior node: test both children; leaf children are queued, interior children
-    // are entered nearest first (the other one is deferred on the stack)
-    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t &nNode) {
+    // cur is a 4-wide node: decode and test its (up to) four child boxes; leaf children that
+    // are hit are queued, interior children are entered nearest first, the others deferred.
+    // With 1/d finite, t along axis k at quantised coordinate q is q*(scale_k/d_k) + (origin_k - o_k)/d_k.
+    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t *ovf, uint32_t &nNode) {
         const float4 *rec = S.anodes + (size_t)cur * 4;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        float tnL, tfL, tnR, tfR;
-        box_span(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tnL, tfL);
-        box_span(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tnR, tfR);
-        if (COUNT) nNode += 2;
-        const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
-        bool hitL = box_live(tnL, tfL), hitR = box_live(tnR, tfR);
-        if (hitL && (left & LEAF_BIT)) { queue_triangle(left & ~LEAF_BIT); hitL = false; }
-        if (hitR && (right & LEAF_BIT)) { queue_triangle(right & ~LEAF_BIT); hitR = false; }
-        if (hitL && hitR) {
-            const bool leftFirst = !(tnR < tnL);
-            cur = leftFirst ? left : right;
-            stack[(sp++) * stride] = leftFirst ? right : left;
-        } else if (hitL) {
-            cur = left;
-        } else if (hitR) {
-            cur = right;
-        } else {
-            cur = REF_NONE;
-            if (sp > 0) cur = stack[(--sp) * stride];
-        }
+        const uint32_t exps = __float_as_uint(q0.w);
+        const float Ax = __uint_as_float((exps & 0xFFu) << 23) * inv.x, Bx = (q0.x - o.x) * inv.x;
+        const float Ay = __uint_as_float(((exps >> 8) & 0xFFu) << 23) * inv.y, By = (q0.y - o.y) * inv.y;
+        const float Az = __uint_as_float(((exps >> 16) & 0xFFu) << 23) * inv.z, Bz = (q0.z - o.z) * inv.z;
+        const uint32_t lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
+        const uint32_t hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
+        const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
+        const uint32_t nrx = ngx ? hix : lox, frx = ngx ? lox : hix;
+        const uint32_t nry = ngy ? hiy : loy, fry = ngy ? loy : hiy;
+        const uint32_t nrz = ngz ? hiz : loz, frz = ngz ? loz : hiz;
+        uint32_t r0 = __float_as_uint(q1.x), r1 = __float_as_uint(q1.y), r2 = __float_as_uint(q1.z), r3 = __float_as_uint(q1.w);
+        // per child: entry distance if its box is hit, +inf otherwise
+#define RT_CHILD(sh, r) child_entry(rtm::madd((float)((nrx >> sh) & 0xFFu), Ax, Bx), rtm::madd((float)((nry >> sh) & 0xFFu), Ay, By), \
+                                    rtm::madd((float)((nrz >> sh) & 0xFFu), Az, Bz), rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), \
+                                    rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz), r)
+        float k0 = RT_CHILD(0, r0), k1 = RT_CHILD(8, r1), k2 = RT_CHILD(16, r2), k3 = RT_CHILD(24, r3);
+#undef RT_CHILD
+        // hit leaf children are queued for the triangle pass and leave the list
+        if (k0 < INFINITY && (r0 & LEAF_BIT)) { queue_triangle(r0 & ~LEAF_BIT); k0 = INFINITY; }
+        if (k1 < INFINITY && (r1 & LEAF_BIT)) { queue_triangle(r1 & ~LEAF_BIT); k1 = INFINITY; }
+        if (k2 < INFINITY && (r2 & LEAF_BIT)) { queue_triangle(r2 & ~LEAF_BIT); k2 = INFINITY; }
+        if (k3 < INFINITY && (r3 & LEAF_BIT)) { queue_triangle(r3 & ~LEAF_BIT); k3 = INFINITY; }
+        if (COUNT) nNode += 4;
+        const int m = (k0 < INFINITY ? 1 : 0) + (k1 < INFINITY ? 1 : 0) + (k2 < INFINITY ? 1 : 0) + (k3 < INFINITY ? 1 : 0);
+        // sort the live interior children by entry distance (5-comparator network)
+#define RT_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
+                                   const uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
+        RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
+#undef RT_CSWAP
+        if (m > 3) push(S, stack, stride, ovf, r3);
+        if (m > 2) push(S, stack, stride, ovf, r2);
+        if (m > 1) push(S, stack, stride, ovf, r1);
+        if (m > 0) cur = r0;
+        else cur = (sp > 0) ? pop(S, stack, stride, ovf) : REF_NONE;
     }
 
     // tests one queued triangle with the reference's hitTriangle arithmetic
@@ -715,6 +740,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
                                                        WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
+    uint32_t *ovf = S.aovf + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -767,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
         }
         // ---- node steps
         const bool step = have && tv.can_step();
-        if (step) tv.node_step(S, stack, BLOCK, cNode);
+        if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
         // ---- triangle pass
         const unsigned long long waiting = __ballot(have && tv.wants_test());
         const unsigned long long stepping = __ballot(have && tv.can_step());
@@ -891,7 +917,8 @@ struct RtContext {
 
     // scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
-    float4 *dANodes = nullptr; uint32_t *dATris = nullptr;     // search index
+    float4 *dANodes = nullptr; uint32_t *dAOvf = nullptr;      // search index: nodes, overflow of the deferred-node stack
+    int accelLdsEntries = 20;
     uint32_t *dRetrySlots = nullptr;
     uint32_t lastRetried = 0;       // rays the last rt_trace_rays call re-traced in reference order
     int64_t nTris = 0, nInterior = 0;
@@ -1055,6 +1082,7 @@ int ensure_sobol(RtContext *ctx) {
 }
 
 size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
+size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.aldsEntries * BLOCK * sizeof(uint32_t); }
 
 }  // namespace
 
@@ -1112,6 +1140,10 @@ int rt_create(RtContext **out, int width, int height, int device) {
         const int v = atoi(env);
         if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
     }
+    if (const char *env = getenv("RT_AMD_ACCEL_LDS_ENTRIES")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 64) ctx->accelLdsEntries = v;
+    }
     for (int b = 0; b < 2; b++) {
         float *base = ctx->dPathMem + (size_t)b * 11 * P;
         PathSoA &q = ctx->q[b];
@@ -1135,7 +1167,7 @@ void rt_destroy(RtContext *ctx) {
     for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->freeEvents) hipEventDestroy(e);
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
-    hipFree(ctx->dANodes); hipFree(ctx->dATris); hipFree(ctx->dRetrySlots);
+    hipFree(ctx->dANodes); hipFree(ctx->dAOvf); hipFree(ctx->dRetrySlots);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
     hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
@@ -1164,24 +1196,22 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     std::vector<float4> hNodes, hTris, hMats; SceneD S;
     int rc = build_device_scene(ctx, tris, n, nodes, m, hNodes, hTris, hMats, S);
     if (rc != RT_OK) return rc;
-    // search index for the extend stage (skipped when RT_AMD_NO_ACCEL is set or the tree is too deep)
+    // search index for the extend stage (skipped when RT_AMD_NO_ACCEL is set)
     rt::Accel accel;
     bool haveAccel = false;
     if (!getenv("RT_AMD_NO_ACCEL")) {
         const float maxAbs = S.cullEps * 1024.0f;
-        int leafMax = 1;
-        if (const char *env = getenv("RT_AMD_LEAF_MAX")) leafMax = atoi(env);
-        if (rt::build_accel(tris, n, maxAbs, leafMax, accel) == RT_OK && accel.maxDepth <= 56) {
+        if (rt::build_accel(tris, n, maxAbs, 1, accel) == RT_OK && accel.directLeaves && accel.wideStack <= 160) {
             haveAccel = true;
             if (getenv("RT_AMD_VERBOSE"))
-                fprintf(stderr, "rt_amd: search index: %zu nodes, depth %d; reference tree height %d\n", accel.nodes.size(), accel.maxDepth, S.stackEntries - 1);
-            S.stackEntries = std::max(S.stackEntries, accel.maxDepth + 1);
+                fprintf(stderr, "rt_amd: search index: %zu binary / %zu 4-wide nodes, depth %d / %d; reference tree height %d\n",
+                        accel.nodes.size(), accel.wide.size(), accel.maxDepth, accel.wideDepth, S.stackEntries - 1);
         }
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dATris);
-    ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dANodes = nullptr; ctx->dATris = nullptr; ctx->haveScene = false;
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dAOvf);
+    ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dANodes = nullptr; ctx->dAOvf = nullptr; ctx->haveScene = false;
     const size_t nodeBytes = std::max<size_t>(hNodes.size(), 4) * sizeof(float4);
     HIP_TRY(ctx, hipMalloc(&ctx->dNodes, nodeBytes));
     HIP_TRY(ctx, hipMalloc(&ctx->dTris, hTris.size() * sizeof(float4)));
@@ -1190,17 +1220,22 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     HIP_TRY(ctx, hipMemcpy(ctx->dTris, hTris.data(), hTris.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMats, hMats.data(), hMats.size() * sizeof(float4), hipMemcpyHostToDevice));
     S.nodes = ctx->dNodes; S.tris = ctx->dTris; S.mats = ctx->dMats;
-    S.anodes = nullptr; S.atris = nullptr; S.arootRef = REF_NONE;
+    S.anodes = nullptr; S.arootRef = REF_NONE; S.aovf = nullptr; S.aovfStride = 0; S.aldsEntries = 1;
     if (haveAccel) {
-        const size_t ab = std::max<size_t>(accel.nodes.size(), 1) * sizeof(rt::AccelNode);
+        const size_t ab = std::max<size_t>(accel.wide.size(), 1) * sizeof(rt::WideNode);
         HIP_TRY(ctx, hipMalloc(&ctx->dANodes, ab));
-        HIP_TRY(ctx, hipMalloc(&ctx->dATris, accel.triIdx.size() * sizeof(uint32_t)));
-        const bool direct = accel.directLeaves;
-        if (!accel.nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->dANodes, accel.nodes.data(), accel.nodes.size() * sizeof(rt::AccelNode), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(ctx->dATris, accel.triIdx.data(), accel.triIdx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        S.anodes = ctx->dANodes; S.atris = direct ? nullptr : ctx->dATris; S.arootRef = accel.rootRef;
+        if (!accel.wide.empty()) HIP_TRY(ctx, hipMemcpy(ctx->dANodes, accel.wide.data(), accel.wide.size() * sizeof(rt::WideNode), hipMemcpyHostToDevice));
+        S.anodes = ctx->dANodes;
+        S.arootRef = accel.wide.empty() ? accel.rootRef : accel.wideRootRef;
         for (int c = 0; c < 3; c++) { S.arootMin[c] = accel.rootMin[c]; S.arootMax[c] = accel.rootMax[c]; }
         S.originLimit = 4.0f * (S.cullEps * 1024.0f);
+        // deferred-node slots: the first ones in LDS, the rest (rarely reached) in global memory
+        const int need = std::max(accel.wideStack, 1);
+        S.aldsEntries = std::min(need, ctx->accelLdsEntries);
+        S.aovfStride = (uint32_t)ctx->numCU * 8u * BLOCK;
+        const size_t ovfEntries = (size_t)std::max(need - S.aldsEntries, 1) * S.aovfStride;
+        HIP_TRY(ctx, hipMalloc(&ctx->dAOvf, ovfEntries * sizeof(uint32_t)));
+        S.aovf = ctx->dAOvf;
     }
     ctx->scene = S; ctx->nTris = n; ctx->nInterior = n - 1; ctx->haveScene = true;
     return RT_OK;
@@ -1321,6 +1356,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     uint32_t *counts = ctx->dQueueCtl, *heads = ctx->dQueueCtl + QCTL_COUNTS;
     const int qstride = NSHARD * CTL_STRIDE;
     const bool useAccel = ctx->opt.accel != 0 && S.anodes != nullptr;
+    const size_t ldsFast = fast_stack_bytes(ctx);
     for (int f = 0; f < count; f++) {
         const int loopNum = first_loopnum + f;
         HIP_TRY(ctx, hipMemsetAsync(ctx->dQueueCtl, 0, QCTL_WORDS * sizeof(uint32_t), st));
@@ -1333,10 +1369,10 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             if (useAccel) {
                 uint32_t *retry = ctx->dQueueCtl + QCTL_COUNTS + QCTL_HEADS + b * CTL_STRIDE;
                 if (cnt) {
-                    hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
+                    hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
                     hipLaunchKernelGGL((k_extend_retry<true>), dim3(ctx->numCU), dim3(BLOCK), lds, st, S, qin, retry, ctx->dRetrySlots, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
                 } else {
-                    hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
+                    hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
                     hipLaunchKernelGGL((k_extend_retry<false>), dim3(ctx->numCU), dim3(BLOCK), lds, st, S, qin, retry, ctx->dRetrySlots, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
                 }
             } else {
@@ -1443,7 +1479,7 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
         const int blocks = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)ctx->numCU * ctx->extendBlocksPerCU);
         uint32_t *counts = dCtl, *heads = dCtl + QCTL_COUNTS, *retry = dCtl + QCTL_COUNTS + QCTL_HEADS;
         if (ctx->opt.accel != 0 && S.anodes != nullptr) {
-            hipLaunchKernelGGL((k_extend_fast<false>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, S, q, cap, counts, heads, dT, dI, retry, dRetry, ctx->dCounters);
+            hipLaunchKernelGGL((k_extend_fast<false>), dim3(blocks), dim3(BLOCK), fast_stack_bytes(ctx), ctx->stream, S, q, cap, counts, heads, dT, dI, retry, dRetry, ctx->dCounters);
             hipLaunchKernelGGL((k_extend_retry<false>), dim3(ctx->numCU), dim3(BLOCK), lds, ctx->stream, S, q, retry, dRetry, dT, dI, ctx->dCounters);
         } else if (ctx->opt.cull) {
             hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, S, q, cap, counts, heads, dT, dI, ctx->dCounters);

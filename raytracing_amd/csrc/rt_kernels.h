@@ -46,9 +46,11 @@ struct SceneD {
     int32_t refill;         // idle lanes of a wave that trigger a fetch of new rays
     int32_t leafBatch;      // lanes waiting at a leaf that make the wave run the triangle tests
     // search index (rt_accel.cpp); anodes == nullptr when absent
-    const float4 *anodes;   // 4 x float4 per node: both children's grown boxes + refs
-    const uint32_t *atris;  // triangle numbers in leaf order
+    const float4 *anodes;   // 4 x float4 per 4-wide node (rt_accel.h WideNode)
     uint32_t arootRef;
+    int32_t aldsEntries;    // deferred-node slots per lane kept in LDS; deeper ones go to aovf
+    uint32_t *aovf;         // overflow slots, [slot][thread of the grid]
+    uint32_t aovfStride;
     float arootMin[3];
     float arootMax[3];
     float originLimit;      // rays starting farther than this from the origin skip the index
