@@ -730,13 +730,11 @@ __global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA 
 // lanes wait for one or nobody can step), and the finish + refill block (when S.refill lanes
 // are finished: their results are written, then they start on new rays from the queue).
 // A finished ray whose result cannot be proven equal to the reference's (tie, unusable ray, or
-// the reference not reaching the triangle) is appended to the retry list and re-traced by
-// k_extend_retry.
+// the reference not reaching the triangle) is traced again in the reference's order on the spot.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const PathSoA Q, const uint32_t cap,
                                                        const uint32_t *__restrict__ qcount, uint32_t *__restrict__ qhead,
                                                        float *__restrict__ hitT, uint32_t *__restrict__ hitTri,
-                                                       uint32_t *__restrict__ retryCount, uint32_t *__restrict__ retrySlots,
                                                        WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -759,13 +757,26 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
         const uint32_t nFree = (uint32_t)__popcll(freeMask);
         const unsigned long long busyMask = __ballot(have && !fin);
         if ((more && nFree >= (uint32_t)S.refill) || busyMask == 0ull) {
+            bool exact = false;
             if (fin) {
-                bool exact = tv.tie || !tv.usable(S);
+                exact = tv.tie || !tv.usable(S);
                 if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
+            }
+            if (__ballot(exact) != 0ull) {
+                // Rare (a few rays per million): trace those rays again in the reference's order,
+                // right here.  The wave's other lanes wait; the other waves of the CU do not.
+                // The lane's deferred-node column is empty at this point and is reused.
+                if (exact) {
+                    float t; uint32_t tri;
+                    closest_triangle<true, COUNT>(S, tv.o, tv.d, stack, BLOCK, t, tri, cNode, cTri);
+                    tv.hitMin = t; tv.best = tri;
+                    atomicAdd(&wc->retraced, 1ull);
+                }
+            }
+            if (fin) {
                 hitT[slot] = tv.hitMin;
                 hitTri[slot] = tv.best;
-                if (exact) retrySlots[atomicAdd(retryCount, 1u)] = slot;
-                else if (COUNT && tv.best != REF_NONE) cHit++;
+                if (COUNT && tv.best != REF_NONE) cHit++;
                 have = false;
             }
             if (!more) {
@@ -799,31 +810,6 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
         const unsigned long long stepping = __ballot(have && tv.can_step());
         if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
             if (have && tv.npend > 0) tv.test_step(S, cTri);
-        }
-    }
-    if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
-}
-
-// Re-traces the rays of the retry list in the reference's order (normally a handful per frame).
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend_retry(const SceneD S, const PathSoA Q, const uint32_t *__restrict__ retryCount,
-                                                        const uint32_t *__restrict__ retrySlots, float *__restrict__ hitT,
-                                                        uint32_t *__restrict__ hitTri, WorkCounters *__restrict__ wc) {
-    extern __shared__ uint32_t lds_stack[];
-    const uint32_t n = *retryCount;
-    if (n != 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wc->retraced, (unsigned long long)n);
-    uint32_t cNode = 0, cTri = 0, cHit = 0;
-    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
-        const uint32_t i = i0 + threadIdx.x;
-        if (i < n) {
-            const uint32_t slot = retrySlots[i];
-            const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
-            const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
-            float t; uint32_t tri;
-            closest_triangle<true, COUNT>(S, o, d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
-            hitT[slot] = t;
-            hitTri[slot] = tri;
-            if (COUNT && tri != REF_NONE) cHit++;
         }
     }
     if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
@@ -919,8 +905,6 @@ struct RtContext {
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
     float4 *dANodes = nullptr; uint32_t *dAOvf = nullptr;      // search index: nodes, overflow of the deferred-node stack
     int accelLdsEntries = 20;
-    uint32_t *dRetrySlots = nullptr;
-    uint32_t lastRetried = 0;       // rays the last rt_trace_rays call re-traced in reference order
     int64_t nTris = 0, nInterior = 0;
     SceneD scene{};
     bool haveScene = false;
@@ -968,7 +952,7 @@ int fail(RtContext *ctx, int code, const std::string &msg) {
 // fill counts of queues 0..B and dequeue heads of queues 0..B-1, NSHARD each, one per 128-byte line
 constexpr int QCTL_COUNTS = (RT_MAX_BOUNCES + 1) * NSHARD * CTL_STRIDE;
 constexpr int QCTL_HEADS = RT_MAX_BOUNCES * NSHARD * CTL_STRIDE;
-constexpr int QCTL_WORDS = QCTL_COUNTS + QCTL_HEADS + RT_MAX_BOUNCES * CTL_STRIDE;  // + one retry count per bounce
+constexpr int QCTL_WORDS = QCTL_COUNTS + QCTL_HEADS;
 
 hipEvent_t take_event(RtContext *ctx) {
     if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
@@ -1082,7 +1066,8 @@ int ensure_sobol(RtContext *ctx) {
 }
 
 size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
-size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.aldsEntries * BLOCK * sizeof(uint32_t); }
+// the fast kernel's LDS column also serves the in-place exact re-trace
+size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)std::max(ctx->scene.aldsEntries, ctx->scene.stackEntries) * BLOCK * sizeof(uint32_t); }
 
 }  // namespace
 
@@ -1127,7 +1112,6 @@ int rt_create(RtContext **out, int width, int height, int device) {
     if (e == hipSuccess) e = hipMalloc(&ctx->dPathMem, 2 * 11 * P * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&ctx->dHitT, P * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&ctx->dHitTri, P * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->dRetrySlots, P * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->dQueueCtl, QCTL_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->dCounters, sizeof(WorkCounters));
     if (e != hipSuccess) {
@@ -1167,7 +1151,7 @@ void rt_destroy(RtContext *ctx) {
     for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->freeEvents) hipEventDestroy(e);
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
-    hipFree(ctx->dANodes); hipFree(ctx->dAOvf); hipFree(ctx->dRetrySlots);
+    hipFree(ctx->dANodes); hipFree(ctx->dAOvf);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
     hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
@@ -1367,14 +1351,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, st));
             if (useAccel) {
-                uint32_t *retry = ctx->dQueueCtl + QCTL_COUNTS + QCTL_HEADS + b * CTL_STRIDE;
-                if (cnt) {
-                    hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
-                    hipLaunchKernelGGL((k_extend_retry<true>), dim3(ctx->numCU), dim3(BLOCK), lds, st, S, qin, retry, ctx->dRetrySlots, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
-                } else {
-                    hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, retry, ctx->dRetrySlots, ctx->dCounters);
-                    hipLaunchKernelGGL((k_extend_retry<false>), dim3(ctx->numCU), dim3(BLOCK), lds, st, S, qin, retry, ctx->dRetrySlots, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
-                }
+                if (cnt) hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
+                else hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
             } else {
 #define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters)
                 if (cull) { if (cnt) LAUNCH_EXT(true, true); else LAUNCH_EXT(true, false); }
@@ -1459,14 +1437,13 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
             soa[(size_t)c * cap + i] = origins[3 * i + c];
             soa[(size_t)(3 + c) * cap + i] = dirs[3 * i + c];
         }
-    float *dRays = nullptr, *dT = nullptr; uint32_t *dI = nullptr, *dCtl = nullptr, *dRetry = nullptr;
+    float *dRays = nullptr, *dT = nullptr; uint32_t *dI = nullptr, *dCtl = nullptr;
     std::vector<uint32_t> ctl(QCTL_WORDS, 0u);
     ctl[0] = (uint32_t)n;
     std::vector<float> hT((size_t)n); std::vector<uint32_t> hI((size_t)n);
     hipError_t e = hipMalloc(&dRays, soa.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&dT, (size_t)cap * 4);
     if (e == hipSuccess) e = hipMalloc(&dI, (size_t)cap * 4);
-    if (e == hipSuccess) e = hipMalloc(&dRetry, (size_t)cap * 4);
     if (e == hipSuccess) e = hipMalloc(&dCtl, QCTL_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(dRays, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dCtl, ctl.data(), QCTL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -1477,10 +1454,9 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
         const SceneD &S = ctx->scene;
         const size_t lds = stack_bytes(ctx);
         const int blocks = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)ctx->numCU * ctx->extendBlocksPerCU);
-        uint32_t *counts = dCtl, *heads = dCtl + QCTL_COUNTS, *retry = dCtl + QCTL_COUNTS + QCTL_HEADS;
+        uint32_t *counts = dCtl, *heads = dCtl + QCTL_COUNTS;
         if (ctx->opt.accel != 0 && S.anodes != nullptr) {
-            hipLaunchKernelGGL((k_extend_fast<false>), dim3(blocks), dim3(BLOCK), fast_stack_bytes(ctx), ctx->stream, S, q, cap, counts, heads, dT, dI, retry, dRetry, ctx->dCounters);
-            hipLaunchKernelGGL((k_extend_retry<false>), dim3(ctx->numCU), dim3(BLOCK), lds, ctx->stream, S, q, retry, dRetry, dT, dI, ctx->dCounters);
+            hipLaunchKernelGGL((k_extend_fast<false>), dim3(blocks), dim3(BLOCK), fast_stack_bytes(ctx), ctx->stream, S, q, cap, counts, heads, dT, dI, ctx->dCounters);
         } else if (ctx->opt.cull) {
             hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, S, q, cap, counts, heads, dT, dI, ctx->dCounters);
         } else {
@@ -1491,16 +1467,13 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(hT.data(), dT, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(hI.data(), dI, (size_t)n * 4, hipMemcpyDeviceToHost);
-    uint32_t retried = 0;
-    if (e == hipSuccess) e = hipMemcpy(&retried, dCtl + QCTL_COUNTS + QCTL_HEADS, 4, hipMemcpyDeviceToHost);
-    hipFree(dRays); hipFree(dT); hipFree(dI); hipFree(dRetry); hipFree(dCtl);
+    hipFree(dRays); hipFree(dT); hipFree(dI); hipFree(dCtl);
     if (e != hipSuccess) return fail(ctx, RT_E_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
     for (int64_t i = 0; i < n; i++) {
         const bool hit = hI[(size_t)i] != REF_NONE;
         t_out[i] = hit ? hT[(size_t)i] : -1.0f;
         id_out[i] = hit ? (int32_t)hI[(size_t)i] : -1;
     }
-    ctx->lastRetried = retried;
     return RT_OK;
 }
 
