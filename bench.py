@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a one-GPU box: every rank uses GPU 0 and the reduce goes through gloo")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,11 +96,16 @@ def main():
     import raytracing_amd as rt
     from raytracing_amd import partition
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg_idx, desc, W, H, bounces, spec = WORKLOADS[args.workload]
     sc, tris, nodes, bvh_s = build_scene(rt, spec)
@@ -135,7 +142,12 @@ def main():
     for s in range(K):
         run_step(Wm + s)
     if dist:
-        partition.reduce_sum_to_root(sum_t, dist)
+        if args.rehearse_on_one_gpu:
+            host = sum_t.cpu()
+            partition.reduce_sum_to_root(host, dist)
+            sum_t.copy_(host)
+        else:
+            partition.reduce_sum_to_root(sum_t, dist)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -146,7 +158,8 @@ def main():
     kernel_ms, launches = r.kernel_time()
     rays_local = stats["rays"]
     if dist:
-        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64,
+                         device="cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -170,7 +183,7 @@ def main():
         bytes_alg = 32.0 * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]
         bytes_per_ray = bytes_alg / max(w["rays"], 1)
         achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        dominant = ("k_extend" if args.no_accel else "k_extend_fast (+k_extend_retry)") if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
+        dominant = ("k_extend" if args.no_accel else "k_extend_fast") if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
         result = {
             "metric": "Mrays/sec (paths x bounces) at 1080p" if H == 1080 else "Mrays/sec (paths x bounces)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,

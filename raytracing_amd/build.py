@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_amd.so")
 SOURCES = ["rt_device.hip", "rt_bvh.cpp", "rt_host.cpp", "rt_scene.cpp", "rt_accel.cpp"]
+MAIN = "rt_main.cpp"
 HEADERS = ["rt_internal.h", "rt_kernels.h", "rt_math.h", "rt_accel.h", os.path.join("..", "..", "include", "rt_amd.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -20,7 +21,9 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + [MAIN]] + [os.path.abspath(__file__)]
+    if not os.path.exists(os.path.join(HERE, "rt_render")):
+        return True
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -32,6 +35,13 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # rt_render: the reference's main loop on top of the C ABI (plain C++ host program)
+    cxx = os.environ.get("CXX", "g++")
+    main_cmd = [cxx, "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "rt_main.cpp"), "-o", os.path.join(HERE, "rt_render"),
+                "-L" + HERE, "-lrt_amd", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(main_cmd), flush=True)
+    subprocess.check_call(main_cmd)
     return LIB
 
 

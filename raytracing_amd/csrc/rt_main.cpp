@@ -1,0 +1,145 @@
+// rt_render: the reference's main loop (main.cpp:50-208) without the window, on top of the C ABI.
+//
+//   rt_render [--demo | --obj FILE SX SY SZ TX TY TZ ... | --synthetic KIND LEVEL COPIES]
+//             [--sphere CX CY CZ R AR AG AB DIFFUSE_RATE MIRROR_RATE] [--size W H] [--spp N]
+//             [--bounces B] [--seed S] [--camera PX PY PZ YAW PITCH FOV] [--exact] [--megakernel]
+//             [--out image.pfm] [--ppm image.ppm]
+//
+// Loads the scene (Model + Scene::pushModel), builds the BVH in the reference's node order
+// (BVHTree::build / buildLinerTree), uploads it (getTexture), then renders N frames with
+// LoopNum = 1..N (cam.LoopIncrease) and an explicit randOrigin stream, and writes the running
+// mean.  The PPM is what the reference's window would show: clamped to [0,1], 8 bits, no gamma
+// (ScreenFragmentShader.glsl:10-14).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "../../include/rt_amd.h"
+}
+
+static int die(const char *what, RtContext *ctx) {
+    std::fprintf(stderr, "rt_render: %s: %s\n", what, rt_last_error(ctx));
+    return 1;
+}
+
+int main(int argc, char **argv) {
+    int W = 1200, H = 800, spp = 16, bounces = 4;     // SCR_WIDTH/SCR_HEIGHT of main.cpp:29-30
+    uint32_t seed = 20221003u;
+    bool exact = false, mega = false, customCam = false, haveGeometry = false;
+    float camArgs[6] = {0, 2, 5, -90, 0, 45};
+    std::string outPfm, outPpm;
+    RtScene *scene = nullptr;
+    if (rt_scene_create(&scene) != RT_OK) return die("rt_scene_create", nullptr);
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { std::fprintf(stderr, "rt_render: %s needs %d values\n", a.c_str(), n); std::exit(2); } };
+        if (a == "--demo") { if (rt_scene_push_demo(scene) != RT_OK) return die("demo scene", nullptr); haveGeometry = true; }
+        else if (a == "--obj") {
+            need(7);
+            const float s[3] = {(float)atof(argv[i + 2]), (float)atof(argv[i + 3]), (float)atof(argv[i + 4])};
+            const float t[3] = {(float)atof(argv[i + 5]), (float)atof(argv[i + 6]), (float)atof(argv[i + 7])};
+            if (rt_scene_push_obj(scene, argv[i + 1], s, t) != RT_OK) return die("load OBJ", nullptr);
+            haveGeometry = true; i += 7;
+        } else if (a == "--synthetic") {
+            need(3);
+            if (rt_scene_push_synthetic(scene, atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), 12345u) != RT_OK) return die("synthetic scene", nullptr);
+            haveGeometry = true; i += 3;
+        } else if (a == "--sphere") {
+            need(9);
+            RtSphere s;
+            for (int k = 0; k < 3; k++) s.center[k] = (float)atof(argv[i + 1 + k]);
+            s.radius = (float)atof(argv[i + 4]);
+            for (int k = 0; k < 3; k++) s.albedo[k] = (float)atof(argv[i + 5 + k]);
+            s.specularRate = (float)atof(argv[i + 8]); s.refractionRate = (float)atof(argv[i + 9]); s.roughness = 0.0f;
+            if (rt_scene_push_sphere(scene, &s) != RT_OK) return die("sphere", nullptr);
+            i += 9;
+        } else if (a == "--size") { need(2); W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
+        else if (a == "--spp") { need(1); spp = atoi(argv[++i]); }
+        else if (a == "--bounces") { need(1); bounces = atoi(argv[++i]); }
+        else if (a == "--seed") { need(1); seed = (uint32_t)strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--camera") { need(6); for (int k = 0; k < 6; k++) camArgs[k] = (float)atof(argv[i + 1 + k]); customCam = true; i += 6; }
+        else if (a == "--exact") exact = true;
+        else if (a == "--megakernel") mega = true;
+        else if (a == "--out") { need(1); outPfm = argv[++i]; }
+        else if (a == "--ppm") { need(1); outPpm = argv[++i]; }
+        else { std::fprintf(stderr, "rt_render: unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (!haveGeometry && rt_scene_push_demo(scene) != RT_OK) return die("demo scene", nullptr);
+    if (spp < 1) { std::fprintf(stderr, "rt_render: --spp must be >= 1\n"); return 2; }
+
+    // tree.build(scene.meshes); tree.buildLinerTree();   main.cpp:113-115
+    const int64_t n = rt_scene_triangle_count(scene);
+    std::vector<RtTriangle> tris((size_t)n);
+    std::vector<RtLinearBVHNode> nodes((size_t)(2 * n - 1));
+    if (rt_scene_get_triangles(scene, tris.data(), n) != RT_OK) return die("scene triangles", nullptr);
+    int64_t m = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    if (rt_bvh_build(tris.data(), n, nodes.data(), (int64_t)nodes.size(), &m) != RT_OK) return die("rt_bvh_build", nullptr);
+    const double bvhMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("triangles: %lld\nbvh nodes: %lld (%.1f ms)\n", (long long)n, (long long)m, bvhMs);   // ObjectTexture.h:73-74
+
+    RtContext *ctx = nullptr;
+    if (rt_create(&ctx, W, H, 0) != RT_OK) return die("rt_create", nullptr);
+    if (rt_scene_upload(ctx, tris.data(), n, nodes.data(), m) != RT_OK) return die("rt_scene_upload", ctx);   // getTexture, main.cpp:120
+    std::vector<RtSphere> spheres((size_t)rt_scene_sphere_count(scene));
+    if (!spheres.empty() && rt_scene_get_spheres(scene, spheres.data(), (int)spheres.size()) != RT_OK) return die("scene spheres", nullptr);
+    if (rt_set_spheres(ctx, spheres.data(), (int)spheres.size()) != RT_OK) return die("rt_set_spheres", ctx);     // scene.setSphere, main.cpp:169
+    RtCamera cam;
+    if (customCam) { if (rt_camera_from_angles(&cam, camArgs, camArgs[3], camArgs[4], camArgs[5], W, H) != RT_OK) return die("camera", nullptr); }
+    else if (rt_camera_default(&cam, W, H) != RT_OK) return die("camera", nullptr);
+    if (rt_set_camera(ctx, &cam) != RT_OK) return die("rt_set_camera", ctx);                                      // main.cpp:156-163
+    RtOptions opt;
+    rt_default_options(&opt);
+    opt.max_bounces = bounces;
+    opt.accel = exact ? 0 : 1;
+    opt.pipeline = mega ? RT_PIPELINE_MEGAKERNEL : RT_PIPELINE_WAVEFRONT;
+    if (rt_set_options(ctx, &opt) != RT_OK) return die("rt_set_options", ctx);
+
+    // the render loop, main.cpp:124-176, in batches of frames
+    std::vector<float> ro((size_t)spp);
+    uint32_t state = seed;
+    for (int f = 0; f < spp; f++) ro[(size_t)f] = rt_rand_origin(&state);                                         // main.cpp:149
+    t0 = std::chrono::steady_clock::now();
+    const int batch = 16;
+    for (int first = 1; first <= spp; first += batch) {
+        const int cnt = (spp - first + 1 < batch) ? spp - first + 1 : batch;
+        if (rt_render_frames(ctx, first, cnt, ro.data() + (first - 1)) != RT_OK) return die("rt_render_frames", ctx);
+    }
+    if (rt_synchronize(ctx) != RT_OK) return die("rt_synchronize", ctx);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    RtStats st;
+    if (rt_get_stats(ctx, &st) != RT_OK) return die("rt_get_stats", ctx);
+    std::printf("LoopNum: %d  frame time: %.3f ms  rays: %llu  %.1f Mrays/s\n", spp, ms / spp, (unsigned long long)st.rays, (double)st.rays / ms * 1e-3);
+
+    std::vector<float> rgb((size_t)W * H * 3);
+    if (rt_read_mean(ctx, rgb.data()) != RT_OK) return die("rt_read_mean", ctx);
+    if (!outPfm.empty()) {          // PFM stores rows bottom to top, as the accumulation buffer does
+        FILE *f = std::fopen(outPfm.c_str(), "wb");
+        if (!f) { std::perror(outPfm.c_str()); return 1; }
+        std::fprintf(f, "PF\n%d %d\n-1.0\n", W, H);
+        std::fwrite(rgb.data(), sizeof(float), rgb.size(), f);
+        std::fclose(f);
+    }
+    if (!outPpm.empty()) {          // top row first: flip
+        FILE *f = std::fopen(outPpm.c_str(), "wb");
+        if (!f) { std::perror(outPpm.c_str()); return 1; }
+        std::fprintf(f, "P6\n%d %d\n255\n", W, H);
+        std::vector<unsigned char> row((size_t)W * 3);
+        for (int y = H - 1; y >= 0; y--) {
+            for (int i = 0; i < W * 3; i++) {
+                float v = rgb[(size_t)y * W * 3 + i];
+                v = !(v > 0.0f) ? 0.0f : (v > 1.0f ? 1.0f : v);
+                row[(size_t)i] = (unsigned char)(v * 255.0f + 0.5f);
+            }
+            std::fwrite(row.data(), 1, row.size(), f);
+        }
+        std::fclose(f);
+    }
+    rt_destroy(ctx);
+    rt_scene_destroy(scene);
+    return 0;
+}

@@ -348,3 +348,24 @@ def test_error_paths():
     assert r.stats()["frames"] == 1
     r.reset()
     assert r.stats()["frames"] == 0 and (r.read_sum() == 0).all()
+
+
+def test_cxx_host_program_matches_python_path(tmp_path):
+    """rt_render (the C++ mirror of the reference's main loop) writes the same image as the
+    ctypes path for the demo scene."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_render")
+    out = tmp_path / "img.pfm"
+    W, H, spp = 120, 80, 5
+    subprocess.check_call([exe, "--demo", "--size", str(W), str(H), "--spp", str(spp), "--out", str(out), "--ppm", str(tmp_path / "img.ppm")])
+    raw = open(out, "rb").read()
+    header = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert raw.startswith(header)
+    got = np.frombuffer(raw[len(header):], dtype="<f4").reshape(H, W, 3)
+    sc = scenes.demo()
+    r = rt.make_renderer(sc, W, H)
+    r.render(1, rt.rand_origins(20221003, spp))
+    assert np.array_equal(got, r.read_mean())
+    ppm = open(tmp_path / "img.ppm", "rb").read()
+    assert ppm.startswith(b"P6\n%d %d\n255\n" % (W, H)) and len(ppm) == len(b"P6\n%d %d\n255\n" % (W, H)) + W * H * 3
