@@ -36,6 +36,7 @@ WORKLOADS = {
 }
 SEED = 20221003
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak
+VALU_PEAK_TFLOPS = 157.3     # MI355X fp32 vector peak
 
 
 def build_scene(rt, spec):
@@ -183,6 +184,21 @@ def main():
         bytes_alg = 32.0 * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]
         bytes_per_ray = bytes_alg / max(w["rays"], 1)
         achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # bytes the kernel's own node layout needs: 16 B per box in the 4-wide index, 32 B per box otherwise
+        node_b = 16.0 if (not args.no_accel and pipeline == rt.PIPELINE_WAVEFRONT) else 32.0
+        layout_bpr = (node_b * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]) / max(w["rays"], 1)
+        layout_gbs = layout_bpr * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # fp32 vector work: 21 ops per box test, 95 per triangle test, 150 per shaded ray
+        flops_per_ray = (21.0 * w["node_tests"] + 95.0 * w["tri_tests"]) / max(w["rays"], 1) + 150.0
+        valu_tflops = flops_per_ray * rays_local / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        # L2-fabric traffic of the dominant kernel from the committed PMC passes of the same workload
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc["workload"] == args.workload and not args.no_accel and args.pipeline == "wavefront":
+                traffic = round((pmc["fetch_size_kb_per_dispatch"] * pmc["fetch_correction"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
+        except (OSError, KeyError, ValueError):
+            traffic = None
         dominant = ("k_extend" if args.no_accel else "k_extend_fast") if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
         result = {
             "metric": "Mrays/sec (paths x bounces) at 1080p" if H == 1080 else "Mrays/sec (paths x bounces)",
@@ -197,8 +213,14 @@ def main():
                        "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
                        "image_mean": float(mean_img.mean())},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch beyond L2 (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json; includes Infinity Cache hits)",
+                         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_local / max(launches, 1)),
+                         "note": "scene data is cache resident: algorithmic bytes are mostly served by L1/L2/Infinity Cache, so `achieved` is not HBM traffic",
                          "bytes_per_ray": round(bytes_per_ray, 1),
+                         "layout_bytes_per_ray": round(layout_bpr, 1), "layout_achieved": round(layout_gbs, 1),
+                         "layout_frac": round(layout_gbs / HBM_PEAK_GBS, 4),
+                         "valu_tflops": round(valu_tflops, 2), "valu_frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                          "nodes_per_ray": round(w["node_tests"] / max(w["rays"], 1), 2),
                          "tris_per_ray": round(w["tri_tests"] / max(w["rays"], 1), 2),
                          "kernel_ms_per_launch": round(kernel_ms / max(launches, 1), 4), "launches": launches,
