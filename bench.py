@@ -77,10 +77,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon1m", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=8)
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
+    ap.add_argument("--resolution", default=None, help="WxH override for sensitivity runs (the named workload's resolution is the default)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a one-GPU box: every rank uses GPU 0 and the reduce goes through gloo")
     args = ap.parse_args()
@@ -109,9 +110,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg_idx, desc, W, H, bounces, spec = WORKLOADS[args.workload]
+    if args.resolution:
+        W, H = (int(v) for v in args.resolution.lower().split("x"))
+        desc += f" [resolution overridden to {W}x{H}]"
     sc, tris, nodes, bvh_s = build_scene(rt, spec)
     cam = rt.camera_default(W, H)
-    pipeline = rt.PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else rt.PIPELINE_MEGAKERNEL
+    pipeline = {"wavefront": rt.PIPELINE_WAVEFRONT, "megakernel": rt.PIPELINE_MEGAKERNEL,
+                "persistent": rt.PIPELINE_PERSISTENT}[args.pipeline]
 
     r = rt.Renderer(W, H, local_rank)
     r.upload(tris, nodes)
@@ -185,7 +190,7 @@ def main():
         bytes_per_ray = bytes_alg / max(w["rays"], 1)
         achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # bytes the kernel's own node layout needs: 16 B per box in the 4-wide index, 32 B per box otherwise
-        node_b = 16.0 if (not args.no_accel and pipeline == rt.PIPELINE_WAVEFRONT) else 32.0
+        node_b = 16.0 if (not args.no_accel and pipeline != rt.PIPELINE_MEGAKERNEL) else 32.0
         layout_bpr = (node_b * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]) / max(w["rays"], 1)
         layout_gbs = layout_bpr * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # fp32 vector work: 21 ops per box test, 95 per triangle test, 150 per shaded ray
@@ -199,7 +204,8 @@ def main():
                 traffic = round((pmc["fetch_size_kb_per_dispatch"] * pmc["fetch_correction"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
         except (OSError, KeyError, ValueError):
             traffic = None
-        dominant = ("k_extend" if args.no_accel else "k_extend_fast") if pipeline == rt.PIPELINE_WAVEFRONT else "k_megakernel"
+        dominant = {rt.PIPELINE_WAVEFRONT: "k_extend" if args.no_accel else "k_extend_fast",
+                    rt.PIPELINE_MEGAKERNEL: "k_megakernel", rt.PIPELINE_PERSISTENT: "k_paths"}[pipeline]
         result = {
             "metric": "Mrays/sec (paths x bounces) at 1080p" if H == 1080 else "Mrays/sec (paths x bounces)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,

@@ -23,6 +23,7 @@ RT_SOBOL_WORDS = 512
 RT_MAX_BOUNCES = 8
 PIPELINE_WAVEFRONT = 0
 PIPELINE_MEGAKERNEL = 1
+PIPELINE_PERSISTENT = 2
 
 # numpy views of the C structs of include/rt_amd.h
 TRIANGLE_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("n", "<f4", (3, 3)), ("tex", "<f4", (3, 2)),

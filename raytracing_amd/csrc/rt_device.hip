@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt_accel.h"
@@ -435,10 +436,11 @@ __device__ __forceinline__ float sphere_test(const RtSphere &s, const vec3 o, co
 // Everything the shader does with a ray after the BVH loop: the rest of hitBVH
 // (frag:457-488), the sphere loop of hitWorld (frag:570-614), the material switch of
 // shading (frag:631-670), the 4*pi scaling (frag:672-673) and the Russian-roulette draw that
-// opens the next iteration (frag:625-630).  Returns true when the path goes on (p holds the
-// next ray); otherwise `sample` is the frame's radiance for the pixel.
+// opens the next iteration (frag:625-630).  sobU/sobV are the frame's Sobol numbers for this
+// bounce (sobol_pair).  Returns true when the path goes on (p holds the next ray); otherwise
+// `sample` is the frame's radiance for the pixel.
 __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
-                                          int bounce, uint32_t loopNum, float uvx, float uvy, vec3 &sample) {
+                                          int bounce, float sobU, float sobV, float uvx, float uvy, vec3 &sample) {
     sample = rtm::mk(0.0f, 0.0f, 0.0f);
     bool hit = false;
     float hitMin = HIT_MIN_INIT;
@@ -493,8 +495,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
         return false;
     }
     if (material == 1) {                                                        // frag:637-641
-        float u, v;
-        sobol_pair(loopNum, (uint32_t)bounce, u, v);
+        float u = sobU, v = sobV;                                               // sobol(2b), sobol(2b+1) of this frame
         cranley_patterson(uvx, uvy, F.width, F.height, u, v);
         // SampleCosineHemisphere, frag:504-515; PI of frag:4 is 3.14159274f in fp32
         const float r = __builtin_sqrtf(u);
@@ -598,7 +599,9 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
                 closest_triangle<CULL, COUNT>(S, p.o, p.d, lds_stack + threadIdx.x, BLOCK, t, tri, cNode, cTri);
                 cRays++;
                 if (COUNT && tri != REF_NONE) cHit++;
-                if (!shade_hit(F, S, p, t, tri, b, loopNum, uvx, uvy, sample)) break;
+                float su, sv;
+                sobol_pair(loopNum, (uint32_t)b, su, sv);
+                if (!shade_hit(F, S, p, t, tri, b, su, sv, uvx, uvy, sample)) break;
             }
             // frag:697 with an fp32 history, and the plain sum
             const float n = (float)(int)loopNum;
@@ -824,6 +827,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
                                                  float *__restrict__ cur) {
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t total = NSHARD * cap;        // cap is a multiple of 64: a wave never straddles shards
+    float su, sv;
+    sobol_pair(loopNum, (uint32_t)bounce, su, sv);
     for (uint32_t v0 = blockIdx.x * BLOCK; v0 < total; v0 += stride) {
         const uint32_t v = v0 + threadIdx.x;
         const uint32_t shardIn = v / cap, idx = v - shardIn * cap;
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
             const float uvx = ((float)px + 0.5f) / (float)F.width;
             const float uvy = ((float)py + 0.5f) / (float)F.height;
             vec3 sample;
-            goOn = shade_hit(F, S, p, hitT[slot], hitTri[slot], bounce, loopNum, uvx, uvy, sample);
+            goOn = shade_hit(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, uvx, uvy, sample);
             if (!goOn && (sample.x != 0.0f || sample.y != 0.0f || sample.z != 0.0f)) {
                 const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
                 cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
@@ -871,6 +876,201 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
     const float c = cur[i];
     mean[i] = rtm::madd(wa, c, wb * mean[i]);
     sum[i] += c;
+}
+
+// ------------------------------------------------------------------ persistent paths
+
+struct BatchD {                     // the frames one launch of k_paths renders
+    int32_t firstLoopNum;
+    int32_t nframes;                // 1..PATHS_MAX_FRAMES
+    float randOrigin[16];
+};
+constexpr int PATHS_MAX_FRAMES = 16;        // frame slot is kept in 4 bits of the lane's pixel word
+
+// Whole paths in one launch: persistent waves, each lane owns one path at a time and runs it
+// from the camera ray to its end (generate, extend, shade, extend, ... as frag:677-689 +
+// frag:617-675 do per pixel), then takes the next (frame, pixel) item.  Several frames are in
+// flight in one launch, so the only point where lanes wait for the slowest ray is the end of
+// the whole batch; a launch per bounce pays that wait (a few hundred microseconds on a
+// 1M-triangle scene) every time.  Samples go to cur[frame slot][pixel]; k_accumulate_batch
+// folds them into the running mean in frame order.
+//
+// Items are numbered frame-major, pixels in 8x8 tiles; a wave reserves a chunk of consecutive
+// items with one atomic and hands them to its idle lanes, the chunk size shrinking towards
+// the end of the batch so that the last waves finish together.
+//
+// FAST: closest hit through the search index with the proof/re-trace of k_extend_fast;
+// otherwise the reference's tree in the reference's order (Trav<CULL>).
+template <bool FAST, bool CULL, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_paths(const SceneD S, const FrameD F, const BatchD B,
+                                                 uint32_t *__restrict__ workHead, float *__restrict__ cur,
+                                                 WorkCounters *__restrict__ wc) {
+    extern __shared__ uint32_t lds_dyn[];
+    // Sobol numbers of every (frame slot, bounce): they do not depend on the pixel (frag:99-104)
+    float *sob = reinterpret_cast<float *>(lds_dyn);
+    const int sobWords = B.nframes * F.maxBounces * 2;
+    for (int t = threadIdx.x; t < sobWords; t += BLOCK) {
+        const int f = t / (F.maxBounces * 2), r = t - f * (F.maxBounces * 2);
+        const uint32_t loopNum = (uint32_t)(B.firstLoopNum + f);
+        uint32_t g = loopNum ^ (loopNum >> 1), acc = 0u;
+        const uint32_t base = (uint32_t)(r >> 1) * 64u + (uint32_t)(r & 1) * 32u;
+        for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
+            if (g & 1u) acc ^= c_sobolV[base + j];
+        sob[t] = (float)acc * (1.0f / 4294967296.0f);
+    }
+    __syncthreads();
+    uint32_t *stack = lds_dyn + ((sobWords + 63) & ~63) + threadIdx.x;
+    uint32_t *ovf = FAST ? S.aovf + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t tilesX = (uint32_t)(F.width + 7) >> 3, tilesY = (uint32_t)(F.height + 7) >> 3;
+    const uint32_t framePix = tilesX * tilesY * 64u;
+    const uint32_t total = framePix * (uint32_t)B.nframes;
+    const size_t frameFloats = (size_t)F.width * (size_t)F.height * 3;
+    const uint32_t nWaves = gridDim.x * (BLOCK / 64);
+
+    uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
+    typename std::conditional<FAST, FastTrav<COUNT>, Trav<CULL, COUNT>>::type tv;
+    tv.cur = REF_NONE;
+    if constexpr (FAST) tv.npend = 0;
+    bool have = false;
+    uint32_t pix = 0;                                   // px | py << 14 | frame slot << 28
+    int bounce = 0;
+    vec3 thr = rtm::mk(0.0f, 0.0f, 0.0f);
+    uint32_t seed = 0;
+    uint32_t cNext = 0, cEnd = 0;                       // wave-uniform: the wave's current chunk of items
+    uint32_t chunk = 256;
+    bool exhausted = false;                             // wave-uniform: the item counter has passed `total`
+    while (true) {
+        bool fin;
+        if constexpr (FAST) fin = have && tv.finished(); else fin = have && tv.done();
+        const uint32_t nFin = (uint32_t)__popcll(__ballot(fin));
+        const uint32_t nEmpty = (uint32_t)__popcll(__ballot(!have));
+        const unsigned long long busyMask = __ballot(have && !fin);
+        const bool more = !exhausted || cNext < cEnd;
+        bool go = busyMask == 0ull;
+        if (more) go = go || (nFin + nEmpty >= (uint32_t)S.refill);
+        else {
+            // no new paths: finished rays are shaded (and their paths continued) once half of
+            // the lanes that still carry a path wait for it
+            const uint32_t live = 64u - nEmpty;
+            const uint32_t need = (live / 2u < (uint32_t)S.refill) ? (live / 2u) : (uint32_t)S.refill;
+            go = go || (nFin >= (need > 0u ? need : 1u));
+        }
+        if (go) {
+            if constexpr (FAST) {
+                bool exact = false;
+                if (fin) {
+                    exact = tv.tie || !tv.usable(S);
+                    if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
+                }
+                if (__ballot(exact) != 0ull) {
+                    if (exact) {
+                        float t; uint32_t tri;
+                        closest_triangle<true, COUNT>(S, tv.o, tv.d, stack, BLOCK, t, tri, cNode, cTri);
+                        tv.hitMin = t; tv.best = tri;
+                        atomicAdd(&wc->retraced, 1ull);
+                    }
+                }
+            }
+            if (fin) {
+                cRays++;
+                if (COUNT && tv.best != REF_NONE) cHit++;
+                const uint32_t px = pix & 0x3FFFu, py = (pix >> 14) & 0x3FFFu, slot = pix >> 28;
+                const float uvx = ((float)px + 0.5f) / (float)F.width;
+                const float uvy = ((float)py + 0.5f) / (float)F.height;
+                const int si = ((int)slot * F.maxBounces + bounce) * 2;
+                Path p;
+                p.o = tv.o; p.d = tv.d; p.thr = thr; p.seed = seed;
+                vec3 sample;
+                const bool goOn = shade_hit(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], uvx, uvy, sample);
+                if (goOn) {
+                    bounce++;
+                    thr = p.thr; seed = p.seed;
+                    tv.begin(S, p.o, p.d, cNode);
+                } else {
+                    float *dst = cur + (size_t)slot * frameFloats + ((size_t)py * (size_t)F.width + px) * 3;
+                    dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
+                    have = false;
+                }
+            }
+            // new paths for the idle lanes (a second round when the wave's chunk ran out half way)
+            for (int round = 0; round < 2; round++) {
+                const unsigned long long freeMask = __ballot(!have);
+                if (freeMask == 0ull || (exhausted && cNext >= cEnd)) break;
+                if (cNext >= cEnd) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)freeMask) - 1;
+                    if ((int)lane == leader) base = atomicAdd(workHead, chunk);
+                    base = __shfl(base, leader);
+                    if (base >= total) { exhausted = true; break; }
+                    cNext = base;
+                    cEnd = (total - base < chunk) ? total : base + chunk;
+                    // guided self-scheduling: about half a share of what is left, 64..256 items
+                    const uint32_t share = ((total - cEnd) / (2u * nWaves)) & ~63u;
+                    chunk = share < 64u ? 64u : (share > 256u ? 256u : share);
+                }
+                const uint32_t nFree = (uint32_t)__popcll(freeMask);
+                const uint32_t left = cEnd - cNext;
+                const uint32_t give = nFree < left ? nFree : left;
+                const uint32_t rank = (uint32_t)__popcll(freeMask & below);
+                if (!have && rank < give) {
+                    const uint32_t idx = cNext + rank;
+                    const uint32_t slot = idx / framePix, rem = idx - slot * framePix;
+                    uint32_t px, py;
+                    if (tile_pixel((int)(rem >> 6), (int)(rem & 63u), F.width, F.height, px, py)) {
+                        Path p; float uvx, uvy;
+                        generate_path(F, B.randOrigin[slot], px, py, p, uvx, uvy);
+                        thr = p.thr; seed = p.seed; bounce = 0;
+                        pix = px | (py << 14) | (slot << 28);
+                        tv.begin(S, p.o, p.d, cNode);
+                        have = true;
+                    }
+                }
+                cNext += give;
+                if (give == nFree) break;
+            }
+            if (__ballot(have) == 0ull) {
+                if (exhausted && cNext >= cEnd) break;
+                continue;
+            }
+        }
+        // ---- advance the rays by one step
+        if constexpr (FAST) {
+            const bool step = have && tv.can_step();
+            if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
+            const unsigned long long waiting = __ballot(have && tv.wants_test());
+            const unsigned long long stepping = __ballot(have && tv.can_step());
+            if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
+                if (have && tv.npend > 0) tv.test_step(S, cTri);
+            }
+        } else {
+            if (have) {
+                if (tv.at_interior()) tv.node_step(S, stack, BLOCK, cNode);
+                else if (tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
+            }
+        }
+    }
+    flush_counters(wc, cRays, cNode, cTri, cHit);
+}
+
+// frag:697 (fp32 history) and the plain sum for the `nframes` samples of a batch, in frame order.
+__global__ __launch_bounds__(BLOCK) void k_accumulate_batch(const float *__restrict__ cur, float *__restrict__ sum,
+                                                            float *__restrict__ mean, const size_t nfloats,
+                                                            const int firstLoopNum, const int nframes) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nfloats) return;
+    float m = mean[i], s = sum[i];
+    for (int f = 0; f < nframes; f++) {
+        const int loopNum = firstLoopNum + f;
+        const float n = (float)loopNum;
+        const float wa = 1.0f / n, wb = (float)(loopNum - 1) / n;
+        const float c = cur[(size_t)f * nfloats + i];
+        m = rtm::madd(wa, c, wb * m);
+        s += c;
+    }
+    mean[i] = m;
+    sum[i] = s;
 }
 
 // Device arithmetic exposed for the primitive-parity test: out[0..4] per element =
@@ -924,6 +1124,9 @@ struct RtContext {
     uint32_t queueCap = 0;          // slots per shard (multiple of 64)
     int extendBlocksPerCU = 7;
     float *dRandOrigin = nullptr; int randCap = 0;
+    // persistent-path pipeline: one sample image per frame of a batch, and the item counter
+    float *dCurBatch = nullptr; int curBatchFrames = 0;
+    uint32_t *dWorkHead = nullptr;
     WorkCounters *dCounters = nullptr;
     uint64_t frames = 0;
     int numCU = 256;
@@ -1155,6 +1358,7 @@ void rt_destroy(RtContext *ctx) {
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
     hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
+    hipFree(ctx->dCurBatch); hipFree(ctx->dWorkHead);
     delete ctx;
 }
 
@@ -1169,7 +1373,7 @@ int rt_set_stream(RtContext *ctx, void *hip_stream) {
 int rt_set_options(RtContext *ctx, const RtOptions *opt) {
     if (!ctx || !opt) return fail(ctx, RT_E_INVALID, "rt_set_options: null pointer");
     if (opt->max_bounces < 1 || opt->max_bounces > RT_MAX_BOUNCES) return fail(ctx, RT_E_INVALID, "rt_set_options: max_bounces must be in 1..8");
-    if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
+    if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL && opt->pipeline != RT_PIPELINE_PERSISTENT) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
     ctx->opt = *opt;
     ctx->frame.maxBounces = opt->max_bounces;
     return RT_OK;
@@ -1327,6 +1531,48 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(e1, st));
         ctx->pendingEvents.emplace_back(e0, e1);
+        ctx->frames += (uint64_t)count;
+        return RT_OK;
+    }
+
+    if (ctx->opt.pipeline == RT_PIPELINE_PERSISTENT) {
+        const size_t nfloats = (size_t)ctx->width * ctx->height * 3;
+        if (!ctx->dCurBatch) {
+            // frames per launch: up to 16, within 2 GiB of sample images and 2^31 items
+            const size_t perFrame = nfloats * sizeof(float);
+            int g = (int)std::min<size_t>(PATHS_MAX_FRAMES, std::max<size_t>(1, ((size_t)2 << 30) / perFrame));
+            g = (int)std::min<size_t>((size_t)g, std::max<size_t>(1, ((size_t)1 << 31) / ((size_t)tiles * 64 + 1)));
+            if (const char *env = getenv("RT_AMD_BATCH_FRAMES")) { const int v = atoi(env); if (v >= 1 && v < g) g = v; }
+            HIP_TRY(ctx, hipMalloc(&ctx->dCurBatch, (size_t)g * perFrame));
+            ctx->curBatchFrames = g;
+        }
+        if (!ctx->dWorkHead) HIP_TRY(ctx, hipMalloc(&ctx->dWorkHead, 128));
+        const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
+        const int blocks = ctx->numCU * ctx->extendBlocksPerCU;
+        const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
+        for (int off = 0; off < count; off += ctx->curBatchFrames) {
+            BatchD B;
+            B.firstLoopNum = first_loopnum + off;
+            B.nframes = std::min(ctx->curBatchFrames, count - off);
+            for (int f = 0; f < PATHS_MAX_FRAMES; f++) B.randOrigin[f] = f < B.nframes ? rand_origin[off + f] : 0.0f;
+            const size_t sobBytes = (size_t)((B.nframes * F.maxBounces * 2 + 63) & ~63) * sizeof(uint32_t);
+            const size_t ldsP = sobBytes + (fast ? fast_stack_bytes(ctx) : lds);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkHead, 0, sizeof(uint32_t), st));
+            hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
+            if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
+            HIP_TRY(ctx, hipEventRecord(e0, st));
+#define LAUNCH_PATHS(A, C, N) hipLaunchKernelGGL((k_paths<A, C, N>), dim3(blocks), dim3(BLOCK), ldsP, st, S, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
+            if (fast) { if (cnt) LAUNCH_PATHS(true, true, true); else LAUNCH_PATHS(true, true, false); }
+            else if (cull) { if (cnt) LAUNCH_PATHS(false, true, true); else LAUNCH_PATHS(false, true, false); }
+            else { if (cnt) LAUNCH_PATHS(false, false, true); else LAUNCH_PATHS(false, false, false); }
+#undef LAUNCH_PATHS
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(e1, st));
+            ctx->pendingEvents.emplace_back(e0, e1);
+            hipLaunchKernelGGL(k_accumulate_batch, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCurBatch, ctx->dSum, ctx->dMean, nfloats,
+                               B.firstLoopNum, B.nframes);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         ctx->frames += (uint64_t)count;
         return RT_OK;
     }

@@ -88,7 +88,8 @@ def test_trace_rays_random_scenes(n, snap):
 
 @pytest.mark.parametrize("pipeline,cull,accel", [(rt.PIPELINE_MEGAKERNEL, False, False), (rt.PIPELINE_MEGAKERNEL, True, False),
                                                  (rt.PIPELINE_WAVEFRONT, False, False), (rt.PIPELINE_WAVEFRONT, True, False),
-                                                 (rt.PIPELINE_WAVEFRONT, True, True)])
+                                                 (rt.PIPELINE_WAVEFRONT, True, True), (rt.PIPELINE_PERSISTENT, True, True),
+                                                 (rt.PIPELINE_PERSISTENT, True, False), (rt.PIPELINE_PERSISTENT, False, False)])
 def test_demo_one_spp_and_running_mean(pipeline, cull, accel):
     W, H = 200, 120
     sc = scenes.demo()
@@ -134,7 +135,8 @@ def test_golden_vectors(golden_dir):
     nodes = g["nodes"].view(rt.NODE_DTYPE)
     sc = scenes.demo()
     cam = rt.camera_default(96, 64)
-    for pipeline, accel in ((rt.PIPELINE_WAVEFRONT, True), (rt.PIPELINE_WAVEFRONT, False), (rt.PIPELINE_MEGAKERNEL, False)):
+    for pipeline, accel in ((rt.PIPELINE_WAVEFRONT, True), (rt.PIPELINE_WAVEFRONT, False), (rt.PIPELINE_MEGAKERNEL, False),
+                            (rt.PIPELINE_PERSISTENT, True), (rt.PIPELINE_PERSISTENT, False)):
         r = rt.Renderer(96, 64)
         r.upload(tris, nodes)
         r.set_spheres(sc.spheres())
@@ -176,7 +178,7 @@ def test_image_sizes_not_multiple_of_tile(W, H):
     cam = rt.camera_default(W, H)
     ro = rt.rand_origins(11, 3)
     want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro)
-    for pipeline in (rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL):
+    for pipeline in (rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL, rt.PIPELINE_PERSISTENT):
         r = rt.Renderer(W, H)
         r.upload(tris, nodes)
         r.set_spheres(sc.spheres())
@@ -205,7 +207,7 @@ def test_spheres_and_bounce_limits(nspheres, bounces):
     cam = rt.camera_default(W, H)
     ro = rt.rand_origins(17, 2)
     want, _ = _oracle_for(tris, nodes, W, H, sph, max_bounces=bounces).render(cam, 1, ro)
-    for pipeline in (rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL):
+    for pipeline in (rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL, rt.PIPELINE_PERSISTENT):
         r = rt.Renderer(W, H)
         r.upload(tris, nodes)
         r.set_spheres(sph)
@@ -228,7 +230,8 @@ def test_mixed_material_scene_and_arbitrary_camera():
     sph = np.zeros(1, dtype=rt.SPHERE_DTYPE)
     sph[0]["center"] = (0, 0, 2); sph[0]["radius"] = 1.0; sph[0]["albedo"] = (0.8, 0.8, 0.8); sph[0]["specularRate"] = 0.5; sph[0]["refractionRate"] = 0.8
     want, st = _oracle_for(tris, nodes, W, H, sph).render(cam, 1, ro, want_stats=True)
-    for pipeline, accel in ((rt.PIPELINE_WAVEFRONT, True), (rt.PIPELINE_WAVEFRONT, False), (rt.PIPELINE_MEGAKERNEL, False)):
+    for pipeline, accel in ((rt.PIPELINE_WAVEFRONT, True), (rt.PIPELINE_WAVEFRONT, False), (rt.PIPELINE_MEGAKERNEL, False),
+                            (rt.PIPELINE_PERSISTENT, True), (rt.PIPELINE_PERSISTENT, False)):
         r = rt.Renderer(W, H)
         r.upload(tris, nodes)
         r.set_spheres(sph)
@@ -271,11 +274,12 @@ def test_synthetic_mesh_parity_and_work_counters():
     cam = rt.camera_default(W, H)
     ro = rt.rand_origins(20221003, 2)
     want, st = _oracle_for(tris, nodes, W, H, None).render(cam, 1, ro, want_stats=True)
-    for accel in (True, False):
+    for accel, pipeline in ((True, rt.PIPELINE_WAVEFRONT), (False, rt.PIPELINE_WAVEFRONT),
+                            (True, rt.PIPELINE_PERSISTENT), (False, rt.PIPELINE_PERSISTENT)):
         r = rt.Renderer(W, H)
         r.upload(tris, nodes)
         r.set_camera(cam)
-        r.set_options(accel=accel, cull=False, count_work=True)
+        r.set_options(accel=accel, cull=False, count_work=True, pipeline=pipeline)
         r.render(1, ro)
         assert np.array_equal(r.read_mean(), want)
         s = r.stats()
@@ -299,7 +303,7 @@ def test_full_size_properties_1080p():
     ro = rt.rand_origins(20221003, 4)
     imgs = {}
     for name, pipeline, accel in (("wf_accel", rt.PIPELINE_WAVEFRONT, True), ("wf_exact", rt.PIPELINE_WAVEFRONT, False),
-                                  ("mega", rt.PIPELINE_MEGAKERNEL, False)):
+                                  ("mega", rt.PIPELINE_MEGAKERNEL, False), ("paths", rt.PIPELINE_PERSISTENT, True)):
         r = rt.Renderer(W, H)
         r.upload(tris, nodes)
         r.set_camera(cam)
@@ -315,6 +319,7 @@ def test_full_size_properties_1080p():
         r.close()
     assert np.array_equal(imgs["wf_accel"], imgs["wf_exact"])
     assert np.array_equal(imgs["wf_accel"], imgs["mega"])
+    assert np.array_equal(imgs["wf_accel"], imgs["paths"])
     osc = _oracle_for(tris, nodes, W, H, None)
     hist = np.zeros((H, W, 3), dtype=np.float32)
     for k in range(4):
