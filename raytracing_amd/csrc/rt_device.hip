@@ -32,6 +32,7 @@ constexpr int BLOCK = 256;          // 4 waves
 constexpr int NSHARD = 16;
 constexpr int CTL_STRIDE = 32;      // words between counters (128 bytes)
 constexpr float HIT_MIN_INIT = 100000.0f;   // frag:633,689
+constexpr int FAST_QUEUE_ENTRIES = 6;        // FastTrav::PEND_MAX: LDS entries per lane ahead of the deferred nodes
 
 // ------------------------------------------------------------------ small device helpers
 
@@ -266,57 +267,46 @@ struct FastTrav {
     bool tie;
     // Triangles met but not yet tested.  Leaves of the index hold one triangle each and are
     // named by their parent, so a node step never has to stop at a leaf: it queues the
-    // triangle here and goes on.  The wave tests queued triangles together (one per lane per
+    // triangle and goes on.  The wave tests queued triangles together (one per lane per
     // pass); testing them one lane at a time costs a full pass of the long triangle code at a
     // few percent lane utilisation.  The search keeps every candidate whatever the order of
-    // the tests.
-    uint32_t pend0, pend1, pend2, pend3, pend4, pend5;
+    // the tests.  The queue is the first PEND_MAX entries of the lane's LDS column, the
+    // deferred nodes follow it.
     int npend;
 
-    static constexpr int PEND_MAX = 6;      // a node step may queue up to 4 triangles
+    static constexpr int PEND_MAX = FAST_QUEUE_ENTRIES;     // a node step may queue up to 4 triangles
 
-    __device__ __forceinline__ bool box_live(float tn, float tf) const {
-        return !(tn > tf) && !(tf < 0.0f) && !(tn > hitCull);
-    }
     // rays this search may be used for: finite 1/d and an origin within the range the growth
     // of the index boxes was sized for
     __device__ __forceinline__ bool usable(const SceneD &S) const {
         const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
         return finite3(inv) && (oM <= S.originLimit);
     }
-    __device__ __forceinline__ float child_entry(float nx_, float ny_, float nz_, float fx_, float fy_, float fz_, uint32_t r) const {
-        const float tn = fmaxf(nx_, fmaxf(ny_, nz_)), tf = fminf(fx_, fminf(fy_, fz_));
-        return (box_live(tn, tf) && r != REF_NONE) ? tn : INFINITY;
-    }
-    // shift-register stack (top in pend0): no dynamic register indexing
-    __device__ __forceinline__ void queue_triangle(uint32_t ti) {
-        pend5 = pend4; pend4 = pend3; pend3 = pend2; pend2 = pend1; pend1 = pend0; pend0 = ti;
+    __device__ __forceinline__ void queue_triangle(uint32_t *col, const int stride, uint32_t ti) {
+        col[npend * stride] = ti;
         npend++;
     }
-    __device__ __forceinline__ uint32_t unqueue_triangle() {
-        const uint32_t r = pend0;
-        pend0 = pend1; pend1 = pend2; pend2 = pend3; pend3 = pend4; pend4 = pend5;
+    __device__ __forceinline__ uint32_t unqueue_triangle(const uint32_t *col, const int stride) {
         npend--;
-        return r;
+        return col[npend * stride];
     }
     // deferred nodes: LDS column of this lane first, global overflow beyond S.aldsEntries
-    __device__ __forceinline__ void push(const SceneD &S, uint32_t *stack, const int stride, uint32_t *ovf, uint32_t v) {
-        if (sp < S.aldsEntries) stack[sp * stride] = v;
+    __device__ __forceinline__ void push(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t v) {
+        if (sp < S.aldsEntries) col[(PEND_MAX + sp) * stride] = v;
         else ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride] = v;
         sp++;
     }
-    __device__ __forceinline__ uint32_t pop(const SceneD &S, const uint32_t *stack, const int stride, const uint32_t *ovf) {
+    __device__ __forceinline__ uint32_t pop(const SceneD &S, const uint32_t *col, const int stride, const uint32_t *ovf) {
         sp--;
-        return (sp < S.aldsEntries) ? stack[sp * stride] : ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride];
+        return (sp < S.aldsEntries) ? col[(PEND_MAX + sp) * stride] : ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride];
     }
 
-    __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
+    __device__ __forceinline__ void begin(const SceneD &S, uint32_t *col, const int stride, const vec3 o_, const vec3 d_, uint32_t &nNode) {
         o = o_; d = d_;
         inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         hitMin = HIT_MIN_INIT;
         hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
         best = REF_NONE; tie = false; sp = 0; npend = 0;
-        pend0 = pend1 = pend2 = pend3 = pend4 = pend5 = 0u;
         // root box (not quantised)
         const float x0 = (S.arootMin[0] - o.x) * inv.x, x1 = (S.arootMax[0] - o.x) * inv.x;
         const float y0 = (S.arootMin[1] - o.y) * inv.y, y1 = (S.arootMax[1] - o.y) * inv.y;
@@ -327,8 +317,8 @@ struct FastTrav {
         cur = REF_NONE;
         // a ray with a zero, NaN or infinite direction component is not searched here at all
         // (with NaN every box would count as hit); the caller sends it to the exact path
-        if (box_live(tn, tf) && usable(S)) {
-            if (S.arootRef & LEAF_BIT) queue_triangle(S.arootRef & ~LEAF_BIT);     // one-triangle scene
+        if (!(tn > tf) && !(tf < 0.0f) && !(tn > hitCull) && usable(S)) {
+            if (S.arootRef & LEAF_BIT) queue_triangle(col, stride, S.arootRef & ~LEAF_BIT);     // one-triangle scene
             else cur = S.arootRef;
         }
     }
@@ -339,7 +329,9 @@ struct FastTrav {
     // cur is a 4-wide node: decode and test its (up to) four child boxes; leaf children that
     // are hit are queued, interior children are entered nearest first, the others deferred.
     // With 1/d finite, t along axis k at quantised coordinate q is q*(scale_k/d_k) + (origin_k - o_k)/d_k.
-    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t *ovf, uint32_t &nNode) {
+    // A child counts as hit unless its box provably is not: max(entry, 0) > min(exit, hitCull)
+    // (a NaN entry counts as 0, a NaN exit as hitCull).
+    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t &nNode) {
         const float4 *rec = S.anodes + (size_t)cur * 4;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
         const uint32_t exps = __float_as_uint(q0.w);
@@ -353,34 +345,50 @@ struct FastTrav {
         const uint32_t nry = ngy ? hiy : loy, fry = ngy ? loy : hiy;
         const uint32_t nrz = ngz ? hiz : loz, frz = ngz ? loz : hiz;
         uint32_t r0 = __float_as_uint(q1.x), r1 = __float_as_uint(q1.y), r2 = __float_as_uint(q1.z), r3 = __float_as_uint(q1.w);
-        // per child: entry distance if its box is hit, +inf otherwise
-#define RT_CHILD(sh, r) child_entry(rtm::madd((float)((nrx >> sh) & 0xFFu), Ax, Bx), rtm::madd((float)((nry >> sh) & 0xFFu), Ay, By), \
-                                    rtm::madd((float)((nrz >> sh) & 0xFFu), Az, Bz), rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), \
-                                    rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz), r)
-        float k0 = RT_CHILD(0, r0), k1 = RT_CHILD(8, r1), k2 = RT_CHILD(16, r2), k3 = RT_CHILD(24, r3);
+        // per child: clamped entry distance and whether the box is hit
+#define RT_CHILD(sh, k, live, r) \
+        const float k = fmaxf(fmaxf(rtm::madd((float)((nrx >> sh) & 0xFFu), Ax, Bx), fmaxf(rtm::madd((float)((nry >> sh) & 0xFFu), Ay, By), \
+                                    rtm::madd((float)((nrz >> sh) & 0xFFu), Az, Bz))), 0.0f); \
+        const bool live = !(k > fminf(fminf(rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), fminf(rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), \
+                                    rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz))), hitCull)) && (r != REF_NONE);
+        RT_CHILD(0, t0, live0, r0) RT_CHILD(8, t1, live1, r1) RT_CHILD(16, t2, live2, r2) RT_CHILD(24, t3, live3, r3)
 #undef RT_CHILD
-        // hit leaf children are queued for the triangle pass and leave the list
-        if (k0 < INFINITY && (r0 & LEAF_BIT)) { queue_triangle(r0 & ~LEAF_BIT); k0 = INFINITY; }
-        if (k1 < INFINITY && (r1 & LEAF_BIT)) { queue_triangle(r1 & ~LEAF_BIT); k1 = INFINITY; }
-        if (k2 < INFINITY && (r2 & LEAF_BIT)) { queue_triangle(r2 & ~LEAF_BIT); k2 = INFINITY; }
-        if (k3 < INFINITY && (r3 & LEAF_BIT)) { queue_triangle(r3 & ~LEAF_BIT); k3 = INFINITY; }
         if (COUNT) nNode += 4;
-        const int m = (k0 < INFINITY ? 1 : 0) + (k1 < INFINITY ? 1 : 0) + (k2 < INFINITY ? 1 : 0) + (k3 < INFINITY ? 1 : 0);
-        // sort the live interior children by entry distance (5-comparator network)
-#define RT_CSWAP(ka, ra, kb, rb) { const bool sw = kb < ka; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
+        // hit leaf children are queued for the triangle pass
+        if (live0 && (r0 & LEAF_BIT)) queue_triangle(col, stride, r0 & ~LEAF_BIT);
+        if (live1 && (r1 & LEAF_BIT)) queue_triangle(col, stride, r1 & ~LEAF_BIT);
+        if (live2 && (r2 & LEAF_BIT)) queue_triangle(col, stride, r2 & ~LEAF_BIT);
+        if (live3 && (r3 & LEAF_BIT)) queue_triangle(col, stride, r3 & ~LEAF_BIT);
+        // hit interior children, farthest first (the others sort last)
+        const bool in0 = live0 && !(r0 & LEAF_BIT), in1 = live1 && !(r1 & LEAF_BIT);
+        const bool in2 = live2 && !(r2 & LEAF_BIT), in3 = live3 && !(r3 & LEAF_BIT);
+        float k0 = in0 ? t0 : -INFINITY, k1 = in1 ? t1 : -INFINITY, k2 = in2 ? t2 : -INFINITY, k3 = in3 ? t3 : -INFINITY;
+        const int m = (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
+#define RT_CSWAP(ka, ra, kb, rb) { const bool sw = kb > ka; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                    const uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
         RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
 #undef RT_CSWAP
-        if (m > 3) push(S, stack, stride, ovf, r3);
-        if (m > 2) push(S, stack, stride, ovf, r2);
-        if (m > 1) push(S, stack, stride, ovf, r1);
-        if (m > 0) cur = r0;
-        else cur = (sp > 0) ? pop(S, stack, stride, ovf) : REF_NONE;
+        if (m == 0) {
+            cur = (sp > 0) ? pop(S, col, stride, ovf) : REF_NONE;
+        } else {
+            // r0..r(m-2) are deferred (the nearest of them on top), r(m-1) is entered now
+            if (sp + 3 <= S.aldsEntries) {
+                // room for three: store them all, the ones beyond m-1 lie above the new top
+                uint32_t *dst = col + (PEND_MAX + sp) * stride;
+                dst[0] = r0; dst[stride] = r1; dst[2 * stride] = r2;
+                sp += m - 1;
+            } else {
+                if (m > 1) push(S, col, stride, ovf, r0);
+                if (m > 2) push(S, col, stride, ovf, r1);
+                if (m > 3) push(S, col, stride, ovf, r2);
+            }
+            cur = (m == 1) ? r0 : ((m == 2) ? r1 : ((m == 3) ? r2 : r3));
+        }
     }
 
     // tests one queued triangle with the reference's hitTriangle arithmetic
-    __device__ __forceinline__ void test_step(const SceneD &S, uint32_t &nTri) {
-        const uint32_t ti = unqueue_triangle();
+    __device__ __forceinline__ void test_step(const SceneD &S, const uint32_t *col, const int stride, uint32_t &nTri) {
+        const uint32_t ti = unqueue_triangle(col, stride);
         const float4 *rec = S.tris + (size_t)ti * 4;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
         const float dis = triangle_test(q0, q1, q2, q3, o, d);
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
                     slot = shard * cap + idx;
                     const vec3 o = rtm::mk(Q.ox[slot], Q.oy[slot], Q.oz[slot]);
                     const vec3 d = rtm::mk(Q.dx[slot], Q.dy[slot], Q.dz[slot]);
-                    tv.begin(S, o, d, cNode);
+                    tv.begin(S, stack, BLOCK, o, d, cNode);
                     have = true;
                 }
             }
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
         const unsigned long long waiting = __ballot(have && tv.wants_test());
         const unsigned long long stepping = __ballot(have && tv.can_step());
         if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
-            if (have && tv.npend > 0) tv.test_step(S, cTri);
+            if (have && tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
         }
     }
     if (COUNT) flush_counters(wc, 0, cNode, cTri, cHit);
@@ -901,8 +909,8 @@ constexpr int PATHS_MAX_FRAMES = 16;        // frame slot is kept in 4 bits of t
 //
 // FAST: closest hit through the search index with the proof/re-trace of k_extend_fast;
 // otherwise the reference's tree in the reference's order (Trav<CULL>).
-template <bool FAST, bool CULL, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_paths(const SceneD S, const FrameD F, const BatchD B,
+template <bool FAST, bool CULL, bool COUNT, int OCC>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths(const SceneD S, const FrameD F, const BatchD B,
                                                  uint32_t *__restrict__ workHead, float *__restrict__ cur,
                                                  WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_dyn[];
@@ -987,7 +995,7 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const SceneD S, const FrameD F,
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
-                    tv.begin(S, p.o, p.d, cNode);
+                    if constexpr (FAST) tv.begin(S, stack, BLOCK, p.o, p.d, cNode); else tv.begin(S, p.o, p.d, cNode);
                 } else {
                     float *dst = cur + (size_t)slot * frameFloats + ((size_t)py * (size_t)F.width + px) * 3;
                     dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
@@ -1023,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const SceneD S, const FrameD F,
                         generate_path(F, B.randOrigin[slot], px, py, p, uvx, uvy);
                         thr = p.thr; seed = p.seed; bounce = 0;
                         pix = px | (py << 14) | (slot << 28);
-                        tv.begin(S, p.o, p.d, cNode);
+                        if constexpr (FAST) tv.begin(S, stack, BLOCK, p.o, p.d, cNode); else tv.begin(S, p.o, p.d, cNode);
                         have = true;
                     }
                 }
@@ -1042,7 +1050,7 @@ __global__ __launch_bounds__(BLOCK) void k_paths(const SceneD S, const FrameD F,
             const unsigned long long waiting = __ballot(have && tv.wants_test());
             const unsigned long long stepping = __ballot(have && tv.can_step());
             if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
-                if (have && tv.npend > 0) tv.test_step(S, cTri);
+                if (have && tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
             }
         } else {
             if (have) {
@@ -1127,6 +1135,7 @@ struct RtContext {
     // persistent-path pipeline: one sample image per frame of a batch, and the item counter
     float *dCurBatch = nullptr; int curBatchFrames = 0;
     uint32_t *dWorkHead = nullptr;
+    int pathsOcc = 6;
     WorkCounters *dCounters = nullptr;
     uint64_t frames = 0;
     int numCU = 256;
@@ -1270,7 +1279,7 @@ int ensure_sobol(RtContext *ctx) {
 
 size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
 // the fast kernel's LDS column also serves the in-place exact re-trace
-size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)std::max(ctx->scene.aldsEntries, ctx->scene.stackEntries) * BLOCK * sizeof(uint32_t); }
+size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)std::max(ctx->scene.aldsEntries + FAST_QUEUE_ENTRIES, ctx->scene.stackEntries) * BLOCK * sizeof(uint32_t); }
 
 }  // namespace
 
@@ -1327,6 +1336,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
         const int v = atoi(env);
         if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
     }
+    if (const char *env = getenv("RT_AMD_PATHS_OCC")) ctx->pathsOcc = atoi(env);
     if (const char *env = getenv("RT_AMD_ACCEL_LDS_ENTRIES")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 64) ctx->accelLdsEntries = v;
@@ -1561,10 +1571,15 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, st));
-#define LAUNCH_PATHS(A, C, N) hipLaunchKernelGGL((k_paths<A, C, N>), dim3(blocks), dim3(BLOCK), ldsP, st, S, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
-            if (fast) { if (cnt) LAUNCH_PATHS(true, true, true); else LAUNCH_PATHS(true, true, false); }
-            else if (cull) { if (cnt) LAUNCH_PATHS(false, true, true); else LAUNCH_PATHS(false, true, false); }
-            else { if (cnt) LAUNCH_PATHS(false, false, true); else LAUNCH_PATHS(false, false, false); }
+#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, st, S, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
+            if (fast) {
+                if (cnt) LAUNCH_PATHS(true, true, true, 5);
+                else if (ctx->pathsOcc == 5) LAUNCH_PATHS(true, true, false, 5);
+                else if (ctx->pathsOcc == 7) LAUNCH_PATHS(true, true, false, 7);
+                else LAUNCH_PATHS(true, true, false, 6);
+            }
+            else if (cull) { if (cnt) LAUNCH_PATHS(false, true, true, 5); else LAUNCH_PATHS(false, true, false, 5); }
+            else { if (cnt) LAUNCH_PATHS(false, false, true, 5); else LAUNCH_PATHS(false, false, false, 5); }
 #undef LAUNCH_PATHS
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(e1, st));
