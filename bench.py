@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon1m", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=8)
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "persistent"])
+    ap.add_argument("--pipeline", default="persistent", choices=["wavefront", "megakernel", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
@@ -186,22 +186,26 @@ def main():
             run_step(Wm + s)
         r.synchronize()
         w = r.stats()
-        bytes_alg = 32.0 * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]
-        bytes_per_ray = bytes_alg / max(w["rays"], 1)
-        achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        # bytes the kernel's own node layout needs: 16 B per box in the 4-wide index, 32 B per box otherwise
+        # Algorithmic bytes per ray segment: boxes tested x bytes per box in the layout the kernel
+        # reads (16 B in the 4-wide quantised index, 32 B in the reference-order binary nodes),
+        # + 36 B per triangle tested + 36 B of material per final hit.
+        rays_w = max(w["rays"], 1)
         node_b = 16.0 if (not args.no_accel and pipeline != rt.PIPELINE_MEGAKERNEL) else 32.0
-        layout_bpr = (node_b * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]) / max(w["rays"], 1)
-        layout_gbs = layout_bpr * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        bytes_per_ray = (node_b * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]) / rays_w
+        achieved = bytes_per_ray * rays_local / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        binary_bpr = (32.0 * w["node_tests"] + 36.0 * w["tri_tests"] + 36.0 * w["tri_hits"]) / rays_w
         # fp32 vector work: 21 ops per box test, 95 per triangle test, 150 per shaded ray
-        flops_per_ray = (21.0 * w["node_tests"] + 95.0 * w["tri_tests"]) / max(w["rays"], 1) + 150.0
+        flops_per_ray = (21.0 * w["node_tests"] + 95.0 * w["tri_tests"]) / rays_w + 150.0
         valu_tflops = flops_per_ray * rays_local / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        # L2-fabric traffic of the dominant kernel from the committed PMC passes of the same workload
+        # traffic beyond L2 of the dominant kernel from the committed PMC passes of the same workload
         traffic = None
+        valu_issue = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc["workload"] == args.workload and not args.no_accel and args.pipeline == "wavefront":
+            if (pmc["workload"] == args.workload and not args.no_accel and args.pipeline == pmc["pipeline"]
+                    and F == pmc["frames_per_dispatch"] and not args.resolution):
                 traffic = round((pmc["fetch_size_kb_per_dispatch"] * pmc["fetch_correction"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
+                valu_issue = pmc.get("valu_issue_slots_busy")
         except (OSError, KeyError, ValueError):
             traffic = None
         dominant = {rt.PIPELINE_WAVEFRONT: "k_extend" if args.no_accel else "k_extend_fast",
@@ -222,13 +226,14 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch beyond L2 (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json; includes Infinity Cache hits)",
                          "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_local / max(launches, 1)),
-                         "note": "scene data is cache resident: algorithmic bytes are mostly served by L1/L2/Infinity Cache, so `achieved` is not HBM traffic",
-                         "bytes_per_ray": round(bytes_per_ray, 1),
-                         "layout_bytes_per_ray": round(layout_bpr, 1), "layout_achieved": round(layout_gbs, 1),
-                         "layout_frac": round(layout_gbs / HBM_PEAK_GBS, 4),
+                         "note": "scene data is cache resident: algorithmic bytes are mostly served by L1/L2/Infinity Cache, "
+                                 "the kernel is bound by vector-ALU issue (see valu_* and DESIGN.md), `achieved` is not HBM traffic",
+                         "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_box": node_b,
+                         "bytes_per_ray_at_32B_per_box": round(binary_bpr, 1),
                          "valu_tflops": round(valu_tflops, 2), "valu_frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
-                         "nodes_per_ray": round(w["node_tests"] / max(w["rays"], 1), 2),
-                         "tris_per_ray": round(w["tri_tests"] / max(w["rays"], 1), 2),
+                         "valu_issue_slots_busy": valu_issue,     # from the PMC run (SQ_INSTS_VALU), see profiles/r01_pmc_traffic.json
+                         "nodes_per_ray": round(w["node_tests"] / rays_w, 2),
+                         "tris_per_ray": round(w["tri_tests"] / rays_w, 2),
                          "kernel_ms_per_launch": round(kernel_ms / max(launches, 1), 4), "launches": launches,
                          "kernel_share_of_wall": round(kernel_ms * 1e-3 / elapsed, 3)},
         }

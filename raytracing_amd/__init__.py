@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIBRARY") or os.path.join(_HERE, "librt_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -244,7 +244,7 @@ class Renderer:
     def set_stream(self, stream_handle):
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
-    def set_options(self, max_bounces=4, pipeline=PIPELINE_WAVEFRONT, cull=True, count_work=False, accel=True):
+    def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True):
         o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 

@@ -949,7 +949,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
     uint32_t cNext = 0, cEnd = 0;                       // wave-uniform: the wave's current chunk of items
     uint32_t chunk = 256;
     bool exhausted = false;                             // wave-uniform: the item counter has passed `total`
+#ifdef RT_EXP_PROFILE
+    unsigned long long xIter = 0, xNode = 0, xTest = 0, xGo = 0;
+#endif
     while (true) {
+#ifdef RT_EXP_PROFILE
+        xIter += 1ull + ((unsigned long long)__popcll(__ballot(have)) << 32);
+#endif
         bool fin;
         if constexpr (FAST) fin = have && tv.finished(); else fin = have && tv.done();
         const uint32_t nFin = (uint32_t)__popcll(__ballot(fin));
@@ -966,6 +972,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
             go = go || (nFin >= (need > 0u ? need : 1u));
         }
         if (go) {
+#ifdef RT_EXP_PROFILE
+            xGo += 1ull + ((unsigned long long)nFin << 32);
+#endif
             if constexpr (FAST) {
                 bool exact = false;
                 if (fin) {
@@ -1046,10 +1055,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
         // ---- advance the rays by one step
         if constexpr (FAST) {
             const bool step = have && tv.can_step();
+#ifdef RT_EXP_PROFILE
+            { const unsigned long long ms = __ballot(step); if (ms) xNode += 1ull + ((unsigned long long)__popcll(ms) << 32); }
+#endif
             if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
             const unsigned long long waiting = __ballot(have && tv.wants_test());
             const unsigned long long stepping = __ballot(have && tv.can_step());
             if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
+#ifdef RT_EXP_PROFILE
+                xTest += 1ull + ((unsigned long long)__popcll(__ballot(have && tv.npend > 0)) << 32);
+#endif
                 if (have && tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
             }
         } else {
@@ -1060,6 +1075,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
         }
     }
     flush_counters(wc, cRays, cNode, cTri, cHit);
+#ifdef RT_EXP_PROFILE
+    // experiment builds only: wave-level block counts (low word) and active lanes (high word)
+    if (lane == 0) {
+        atomicAdd(&wc->node_tests, xIter & 0xFFFFFFFFull); atomicAdd(&wc->node_tests, (xIter >> 32) << 32);
+        atomicAdd(&wc->tri_tests, xNode & 0xFFFFFFFFull); atomicAdd(&wc->tri_tests, (xNode >> 32) << 32);
+        atomicAdd(&wc->tri_hits, xTest & 0xFFFFFFFFull); atomicAdd(&wc->tri_hits, (xTest >> 32) << 32);
+        atomicAdd(&wc->retraced, xGo & 0xFFFFFFFFull); atomicAdd(&wc->retraced, (xGo >> 32) << 32);
+    }
+#endif
 }
 
 // frag:697 (fp32 history) and the plain sum for the `nframes` samples of a batch, in frame order.
@@ -1135,7 +1159,8 @@ struct RtContext {
     // persistent-path pipeline: one sample image per frame of a batch, and the item counter
     float *dCurBatch = nullptr; int curBatchFrames = 0;
     uint32_t *dWorkHead = nullptr;
-    int pathsOcc = 6;
+    int pathsOcc = 6;           // waves per SIMD the path kernel is compiled for (5, 6 or 7)
+    int pathsLeafBatch = 8;     // lanes waiting for a triangle pass that trigger one in the path kernel
     WorkCounters *dCounters = nullptr;
     uint64_t frames = 0;
     int numCU = 256;
@@ -1288,7 +1313,7 @@ extern "C" {
 int rt_default_options(RtOptions *out) {
     if (!out) return fail(nullptr, RT_E_INVALID, "rt_default_options: null pointer");
     out->max_bounces = 4;
-    out->pipeline = RT_PIPELINE_WAVEFRONT;
+    out->pipeline = RT_PIPELINE_PERSISTENT;
     out->cull = 1;
     out->count_work = 0;
     out->accel = 1;
@@ -1337,6 +1362,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
         if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
     }
     if (const char *env = getenv("RT_AMD_PATHS_OCC")) ctx->pathsOcc = atoi(env);
+    if (const char *env = getenv("RT_AMD_PATHS_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) ctx->pathsLeafBatch = v; }
     if (const char *env = getenv("RT_AMD_ACCEL_LDS_ENTRIES")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 64) ctx->accelLdsEntries = v;
@@ -1558,8 +1584,11 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         }
         if (!ctx->dWorkHead) HIP_TRY(ctx, hipMalloc(&ctx->dWorkHead, 128));
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
-        const int blocks = ctx->numCU * ctx->extendBlocksPerCU;
+        // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
+        const int blocks = ctx->numCU * (fast ? std::min(std::max(ctx->pathsOcc, 5), 7) : 5);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
+        SceneD Sp = S;
+        Sp.leafBatch = ctx->pathsLeafBatch;
         for (int off = 0; off < count; off += ctx->curBatchFrames) {
             BatchD B;
             B.firstLoopNum = first_loopnum + off;
@@ -1571,7 +1600,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, st));
-#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, st, S, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
+#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, st, Sp, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
             if (fast) {
                 if (cnt) LAUNCH_PATHS(true, true, true, 5);
                 else if (ctx->pathsOcc == 5) LAUNCH_PATHS(true, true, false, 5);

@@ -68,7 +68,7 @@ def test_host_side_argument_checks():
     assert rt.lib.rt_version().startswith(b"rt_amd")
     o = rt.RtOptions()
     assert rt.lib.rt_default_options(C.byref(o)) == 0
-    assert (o.max_bounces, o.pipeline, o.cull, o.count_work, o.accel) == (4, 0, 1, 0, 1)
+    assert (o.max_bounces, o.pipeline, o.cull, o.count_work, o.accel) == (4, rt.PIPELINE_PERSISTENT, 1, 0, 1)
 
 
 def test_create_without_gpu_fails_loudly():

@@ -127,6 +127,31 @@ def test_demo_one_spp_and_running_mean(pipeline, cull, accel):
     assert np.sqrt(np.mean((ssum - want) ** 2)) < 1e-5
 
 
+def test_persistent_pipeline_frame_batches():
+    """37 frames in one call: the persistent pipeline renders them 16 per launch (three launches,
+    the last one partial) and must reproduce the frame-by-frame running mean and sum."""
+    W, H = 72, 40
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(99, 37)
+    want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro)
+    res = {}
+    for pipeline in (rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        r.set_options(pipeline=pipeline)
+        r.render(1, ro)
+        res[pipeline] = (r.read_mean(), r.read_sum(), r.stats()["rays"])
+        r.close()
+    assert np.array_equal(res[rt.PIPELINE_PERSISTENT][0], want)
+    assert np.array_equal(res[rt.PIPELINE_PERSISTENT][0], res[rt.PIPELINE_WAVEFRONT][0])
+    assert np.array_equal(res[rt.PIPELINE_PERSISTENT][1], res[rt.PIPELINE_WAVEFRONT][1])
+    assert res[rt.PIPELINE_PERSISTENT][2] == res[rt.PIPELINE_WAVEFRONT][2]
+
+
 def test_golden_vectors(golden_dir):
     """Committed expected values (made by the oracle from the reference's scene files)."""
     import os

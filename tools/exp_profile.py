@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Experiment: prints the wave-level block counts of a library built with -DRT_EXP_PROFILE."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracing_amd as rt
+sc = rt.Scene(); sc.push_synthetic(0, 8, 1, 12345)
+r = rt.make_renderer(sc, 1920, 1080, 0, max_bounces=4, pipeline=2)
+ro = rt.rand_origins(20221003, 8)
+r.render(1, ro); r.synchronize()
+st = r.stats()
+rays = st["rays"]
+def split(v): return v & 0xFFFFFFFF, v >> 32
+for name, key in (("iterations", "node_tests"), ("node blocks", "tri_tests"), ("test blocks", "tri_hits"), ("go blocks", "retraced")):
+    n, lanes = split(st[key])
+    print(f"{name:12s} count {n:10d}  lanes {lanes:12d}  lanes/block {lanes / max(n, 1):5.1f}  blocks per ray {n / rays:.4f}  lane-steps per ray {lanes / rays:.2f}")
+print("rays", rays)

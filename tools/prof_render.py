@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bounces", type=int, default=4)
-    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=2)
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--count", action="store_true")
     a = ap.parse_args()
