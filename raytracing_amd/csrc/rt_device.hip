@@ -441,6 +441,13 @@ __device__ __forceinline__ float sphere_test(const RtSphere &s, const vec3 o, co
     return -1.0f;
 }
 
+// frag:494-500: tangent and bitangent of a normal
+__host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tangent, vec3 &bitangent) {
+    const vec3 helper = (fabsf(nrm.x) > 0.999f) ? rtm::mk(0.0f, 0.0f, 1.0f) : rtm::mk(1.0f, 0.0f, 0.0f);
+    tangent = rtm::normalize(rtm::cross(nrm, helper));
+    bitangent = rtm::normalize(rtm::cross(nrm, tangent));
+}
+
 // Everything the shader does with a ray after the BVH loop: the rest of hitBVH
 // (frag:457-488), the sphere loop of hitWorld (frag:570-614), the material switch of
 // shading (frag:631-670), the 4*pi scaling (frag:672-673) and the Russian-roulette draw that
@@ -455,16 +462,19 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
     vec3 pos = rtm::mk(0, 0, 0), nrm = rtm::mk(0, 0, 0), albedo = rtm::mk(0, 0, 0);
     int material = -1;
     float refraction = 1.0f;
+    // tangent frame of the hit: taken from the triangle's record, computed for a sphere
+    bool recFrame = false;
+    vec3 tangent = rtm::mk(0, 0, 0), bitangent = rtm::mk(0, 0, 0);
     if (tri != REF_NONE) {
-        const float4 *rec = S.tris + (size_t)tri * 4;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-        const vec3 v0 = rtm::mk(q0.x, q0.y, q0.z), v1 = rtm::mk(q0.w, q1.x, q1.y), v2 = rtm::mk(q1.z, q1.w, q2.x);
+        const float4 *m = S.mats + (size_t)tri * 5;
+        const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4];
         pos = rtm::along(p.o, tTri, p.d);                                       // frag:458
-        nrm = rtm::normalize(rtm::cross(rtm::sub(v2, v0), rtm::sub(v1, v0)));   // frag:296-300
-        if (rtm::dot(nrm, p.d) > 0.0f) nrm = rtm::neg(nrm);
+        nrm = rtm::mk(m2.y, m2.z, m2.w);                                        // frag:296-300, precomputed
+        tangent = rtm::mk(m3.x, m3.y, m3.z);
+        bitangent = rtm::mk(m3.w, m4.x, m4.y);
+        recFrame = true;
+        if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
         const float temp = rand01(p.seed);                                      // frag:462
-        const float4 *m = S.mats + (size_t)tri * 3;
-        const float4 m0 = m[0], m1 = m[1], m2 = m[2];
         const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
         const float ksx = m1.z, ksy = m1.w;
         if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }             // length(ka) > 0
@@ -493,6 +503,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
             }
             pos = rtm::along(p.o, hitMin, p.d);
             nrm = rtm::sub(pos, centre);
+            recFrame = false;
         }
     }
     if (!hit) return false;         // a miss can never reach a light afterwards (frag:655-672)
@@ -512,10 +523,10 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
         rtm::sincos_2pi_range(theta, sn, cs);
         const float x = r * cs, y = r * sn;
         const float z = __builtin_sqrtf(rtm::madd(-y, y, rtm::madd(-x, x, 1.0f)));
-        // toNormalHemisphere, frag:494-500
-        const vec3 helper = (fabsf(nrm.x) > 0.999f) ? rtm::mk(0.0f, 0.0f, 1.0f) : rtm::mk(1.0f, 0.0f, 0.0f);
-        const vec3 tangent = rtm::normalize(rtm::cross(nrm, helper));
-        const vec3 bitangent = rtm::normalize(rtm::cross(nrm, tangent));
+        // toNormalHemisphere, frag:494-500.  For a triangle the frame depends on the triangle
+        // only and comes from its record (tangent_frame below, same arithmetic; negating the
+        // normal negates the tangent and leaves the bitangent, exactly).
+        if (!recFrame) tangent_frame(nrm, tangent, bitangent);
         const vec3 L = rtm::mk(rtm::madd(z, nrm.x, rtm::madd(y, bitangent.x, x * tangent.x)),
                                rtm::madd(z, nrm.y, rtm::madd(y, bitangent.y, x * tangent.y)),
                                rtm::madd(z, nrm.z, rtm::madd(y, bitangent.z, x * tangent.z)));
@@ -1257,7 +1268,7 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
         uint32_t w[4] = {ref_of(k + 1), ref_of(nd.offsetOrRc), (uint32_t)nd.axis, 0u};
         std::memcpy(&o[3], w, 16);
     }
-    hTris.resize((size_t)n * 4); hMats.resize((size_t)n * 3);
+    hTris.resize((size_t)n * 4); hMats.resize((size_t)n * 5);
     for (int64_t i = 0; i < n; i++) {
         const RtTriangle &t = tris[i];
         const vec3 v0 = rtm::mk(t.v[0][0], t.v[0][1], t.v[0][2]);
@@ -1269,9 +1280,16 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
         hTris[(size_t)i * 4 + 1] = make_float4(v1.y, v1.z, v2.x, v2.y);
         hTris[(size_t)i * 4 + 2] = make_float4(v2.z, N.x, N.y, N.z);
         hTris[(size_t)i * 4 + 3] = make_float4(D, 0.0f, 0.0f, 0.0f);
-        hMats[(size_t)i * 3 + 0] = make_float4(t.ka[0], t.ka[1], t.ka[2], t.kd[0]);
-        hMats[(size_t)i * 3 + 1] = make_float4(t.kd[1], t.kd[2], t.ks[0], t.ks[1]);
-        hMats[(size_t)i * 3 + 2] = make_float4(t.ks[2], 0.0f, 0.0f, 0.0f);
+        // shading record: materials, the shading normal of getTriangleNormal (frag:296-300; the
+        // operand order differs from N above) and its tangent frame (frag:494-500)
+        const vec3 nS = rtm::normalize(rtm::cross(rtm::sub(v2, v0), rtm::sub(v1, v0)));
+        vec3 tg, bt;
+        tangent_frame(nS, tg, bt);
+        hMats[(size_t)i * 5 + 0] = make_float4(t.ka[0], t.ka[1], t.ka[2], t.kd[0]);
+        hMats[(size_t)i * 5 + 1] = make_float4(t.kd[1], t.kd[2], t.ks[0], t.ks[1]);
+        hMats[(size_t)i * 5 + 2] = make_float4(t.ks[2], nS.x, nS.y, nS.z);
+        hMats[(size_t)i * 5 + 3] = make_float4(tg.x, tg.y, tg.z, bt.x);
+        hMats[(size_t)i * 5 + 4] = make_float4(bt.y, bt.z, 0.0f, 0.0f);
     }
     S = SceneD{};
     float maxAbs = 0.0f;

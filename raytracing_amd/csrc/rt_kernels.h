@@ -17,7 +17,9 @@
 //   tris:  one 64-byte record per triangle: v0 v1 v2, the unit normal N and plane offset D
 //          that hitTriangle (frag:257-262) recomputes for every ray (they depend on the
 //          triangle only, and are computed with the same arithmetic).
-//   mats:  one 48-byte record per triangle: ka kd ks (frag:220-230), read once per hit.
+//   mats:  one 80-byte record per triangle, read once per final hit: ka kd ks (frag:220-230),
+//          the shading normal (frag:296-300) and its tangent frame (frag:494-500), which depend
+//          on the triangle only.
 // The reference's 33-float triangle texel and 9-float node texel carry 15 resp. 0 floats the
 // shader never uses (normals, uvs: frag:196-218).
 #pragma once
@@ -37,7 +39,7 @@ constexpr uint32_t REF_NONE = 0xFFFFFFFFu;     // also "no triangle"
 struct SceneD {
     const float4 *nodes;    // 4 x float4 per interior node
     const float4 *tris;     // 4 x float4 per triangle
-    const float4 *mats;     // 3 x float4 per triangle
+    const float4 *mats;     // 5 x float4 per triangle
     float rootMin[3];
     float rootMax[3];
     uint32_t rootRef;       // LEAF_BIT|0 for a one-triangle scene, 0 otherwise, REF_NONE if empty
