@@ -96,11 +96,16 @@ typedef struct RtOptions {
     int32_t cull;           /* 1: skip boxes that provably cannot hold a closer hit (same image);
                                0: visit exactly the boxes the reference visits */
     int32_t count_work;     /* 1: maintain node_tests/tri_tests/tri_hits (slower kernels) */
-    int32_t accel;          /* 1 (wavefront pipeline only): find the closest accepted triangle through
+    int32_t accel;          /* 1 (persistent and wavefront pipelines): find the closest accepted triangle through
                                a SAH search index built at upload, prove with one exact box test that
                                the reference's traversal reaches it, and re-trace in the reference's
                                order the rays for which the proof fails (same image);
                                0: always traverse the reference's tree in the reference's order */
+    int32_t history8;       /* 0 (default): the running mean is kept in fp32;
+                               1: emulate the reference's history texture, an 8-bit GL_RGB attachment
+                               (RT_Screen.h:61): after every frame the mean is clamped to [0,1] and
+                               rounded to a multiple of 1/255 (NaN becomes 0).  The plain sum is
+                               not affected. */
 } RtOptions;
 #define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
 #define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */
@@ -147,6 +152,32 @@ float rt_sobol(const uint32_t v[RT_SOBOL_WORDS], uint32_t d, uint32_t i);
 int rt_camera_from_angles(RtCamera *out, const float pos[3], float yaw_deg, float pitch_deg,
                           float fov_deg, int width, int height);
 int rt_camera_default(RtCamera *out, int width, int height);
+
+/* class Camera, Camera.h:16-139: the interactive camera with its state.  Every change resets
+ * LoopNum to 0 (Camera.h:45,59,94,109): the caller then calls rt_reset() and numbers frames
+ * from 1 again, as main.cpp does through cam.LoopIncrease(). */
+typedef struct RtCameraRig {
+    float cameraPos[3], cameraFront[3], cameraUp[3], cameraRight[3], worldUp[3];
+    float fov, Pitch, Yaw;          /* degrees */
+    float cameraSpeed;
+    int32_t firstMouse;
+    float lastX, lastY;
+    float ScreenRatio, halfH, halfW;
+    float LeftBottomCorner[3];
+    int32_t LoopNum;
+} RtCameraRig;
+#define RT_CAMERA_FORWARD 0     /* enum Camera_Movement, Camera.h:9-14 */
+#define RT_CAMERA_BACKWARD 1
+#define RT_CAMERA_LEFT 2
+#define RT_CAMERA_RIGHT 3
+int rt_camera_rig_init(RtCameraRig *rig, int width, int height);                  /* Camera.h:18-31 */
+int rt_camera_rig_update_vectors(RtCameraRig *rig);                               /* Camera.h:33-46 */
+int rt_camera_rig_update_fov(RtCameraRig *rig, float offset);                     /* Camera.h:47-60: fov clamped to 1..45 */
+int rt_camera_rig_update_front(RtCameraRig *rig, float xpos, float ypos);         /* Camera.h:61-87: 0.03 deg per pixel, pitch clamped to +-89 */
+int rt_camera_rig_update_screen_ratio(RtCameraRig *rig, int width, int height);   /* Camera.h:88-95 */
+int rt_camera_rig_process_keyboard(RtCameraRig *rig, int direction, float delta_time);   /* Camera.h:96-110 */
+int rt_camera_rig_loop_increase(RtCameraRig *rig);                                /* Camera.h:111-113 */
+int rt_camera_rig_uniforms(const RtCameraRig *rig, RtCamera *out);                /* main.cpp:156-163 */
 
 /* Replaces CPURandomInit/GetCPURandom, Tool.h:8-14, which seed from time(): an explicit
  * 32-bit generator.  *state is advanced; returns 874264.0f * (u + 1.0f), u in [0,1), the

@@ -43,9 +43,19 @@ class RtStats(C.Structure):
                 ("tri_hits", C.c_uint64), ("frames", C.c_uint64), ("retraced", C.c_uint64)]
 
 
+class RtCameraRig(C.Structure):
+    """class Camera of the reference (Camera.h:16-139), field for field."""
+    _fields_ = [("cameraPos", C.c_float * 3), ("cameraFront", C.c_float * 3), ("cameraUp", C.c_float * 3),
+                ("cameraRight", C.c_float * 3), ("worldUp", C.c_float * 3),
+                ("fov", C.c_float), ("Pitch", C.c_float), ("Yaw", C.c_float), ("cameraSpeed", C.c_float),
+                ("firstMouse", C.c_int32), ("lastX", C.c_float), ("lastY", C.c_float),
+                ("ScreenRatio", C.c_float), ("halfH", C.c_float), ("halfW", C.c_float),
+                ("LeftBottomCorner", C.c_float * 3), ("LoopNum", C.c_int32)]
+
+
 class RtOptions(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
-                ("count_work", C.c_int32), ("accel", C.c_int32)]
+                ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32)]
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
@@ -60,6 +70,14 @@ _PROTOS = {
     "rt_camera_from_angles": (_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, _int, _int]),
     "rt_camera_default": (_int, [_vp, _int, _int]),
     "rt_rand_origin": (C.c_float, [C.POINTER(C.c_uint32)]),
+    "rt_camera_rig_init": (_int, [C.POINTER(RtCameraRig), _int, _int]),
+    "rt_camera_rig_update_vectors": (_int, [C.POINTER(RtCameraRig)]),
+    "rt_camera_rig_update_fov": (_int, [C.POINTER(RtCameraRig), C.c_float]),
+    "rt_camera_rig_update_front": (_int, [C.POINTER(RtCameraRig), C.c_float, C.c_float]),
+    "rt_camera_rig_update_screen_ratio": (_int, [C.POINTER(RtCameraRig), _int, _int]),
+    "rt_camera_rig_process_keyboard": (_int, [C.POINTER(RtCameraRig), _int, C.c_float]),
+    "rt_camera_rig_loop_increase": (_int, [C.POINTER(RtCameraRig)]),
+    "rt_camera_rig_uniforms": (_int, [C.POINTER(RtCameraRig), _vp]),
     "rt_scene_create": (_int, [C.POINTER(_vp)]),
     "rt_scene_destroy": (None, [_vp]),
     "rt_scene_push_obj": (_int, [_vp, C.c_char_p, _vp, _vp]),
@@ -135,6 +153,35 @@ def camera_from_angles(pos, yaw, pitch, fov, width, height):
     p = np.asarray(pos, dtype=np.float32)
     _check(lib.rt_camera_from_angles(_ptr(cam), _ptr(p), yaw, pitch, fov, width, height))
     return cam
+
+
+class CameraRig:
+    """The reference's interactive camera (Camera.h); `uniforms()` gives what rt_set_camera takes."""
+    FORWARD, BACKWARD, LEFT, RIGHT = 0, 1, 2, 3
+
+    def __init__(self, width, height):
+        self.s = RtCameraRig()
+        _check(lib.rt_camera_rig_init(C.byref(self.s), width, height))
+
+    def update_fov(self, offset):
+        _check(lib.rt_camera_rig_update_fov(C.byref(self.s), offset))
+
+    def update_front(self, xpos, ypos):
+        _check(lib.rt_camera_rig_update_front(C.byref(self.s), xpos, ypos))
+
+    def update_screen_ratio(self, width, height):
+        _check(lib.rt_camera_rig_update_screen_ratio(C.byref(self.s), width, height))
+
+    def process_keyboard(self, direction, delta_time):
+        _check(lib.rt_camera_rig_process_keyboard(C.byref(self.s), direction, delta_time))
+
+    def loop_increase(self):
+        _check(lib.rt_camera_rig_loop_increase(C.byref(self.s)))
+
+    def uniforms(self):
+        cam = np.zeros(1, dtype=CAMERA_DTYPE)
+        _check(lib.rt_camera_rig_uniforms(C.byref(self.s), _ptr(cam)))
+        return cam
 
 
 def rand_origins(seed, count):
@@ -244,8 +291,9 @@ class Renderer:
     def set_stream(self, stream_handle):
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
-    def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True):
-        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel))
+    def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True,
+                    history8=False):
+        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 
     def upload(self, tris, nodes):

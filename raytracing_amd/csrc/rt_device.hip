@@ -574,6 +574,12 @@ __device__ __forceinline__ bool tile_pixel(int tile, int lane, int width, int he
     return px < (uint32_t)width && py < (uint32_t)height;
 }
 
+// What an 8-bit unsigned-normalised colour attachment keeps of a value (RT_Screen.h:61).
+__device__ __forceinline__ float store_unorm8(float v) {
+    const float c = (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f;      // NaN -> 0
+    return floorf(c * 255.0f + 0.5f) / 255.0f;
+}
+
 __device__ __forceinline__ void flush_counters(WorkCounters *wc, uint32_t rays, uint32_t nNode, uint32_t nTri, uint32_t nHit) {
     // wave-level reduction, then one atomic per wave and counter
     for (int off = 32; off > 0; off >>= 1) {
@@ -597,7 +603,7 @@ template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const FrameD F, const int firstLoopNum,
                                                       const int count, const float *__restrict__ randOrigin,
                                                       float *__restrict__ sum, float *__restrict__ mean,
-                                                      WorkCounters *__restrict__ wc) {
+                                                      const int history8, WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
             m0 = rtm::madd(wa, sample.x, wb * m0);
             m1 = rtm::madd(wa, sample.y, wb * m1);
             m2 = rtm::madd(wa, sample.z, wb * m2);
+            if (history8) { m0 = store_unorm8(m0); m1 = store_unorm8(m1); m2 = store_unorm8(m2); }
             s0 += sample.x; s1 += sample.y; s2 += sample.z;
         }
         sum[o3] = s0; sum[o3 + 1] = s1; sum[o3 + 2] = s2;
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
 __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ cur, float *__restrict__ sum,
                                                       float *__restrict__ mean, const size_t nfloats, const int loopNum,
                                                       const uint32_t *__restrict__ qcounts, const int nqueues,
-                                                      WorkCounters *__restrict__ wc) {
+                                                      const int history8, WorkCounters *__restrict__ wc) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) {
         unsigned long long rays = 0;
@@ -893,7 +900,8 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
     const float n = (float)loopNum;
     const float wa = 1.0f / n, wb = (float)(loopNum - 1) / n;
     const float c = cur[i];
-    mean[i] = rtm::madd(wa, c, wb * mean[i]);
+    const float m = rtm::madd(wa, c, wb * mean[i]);
+    mean[i] = history8 ? store_unorm8(m) : m;
     sum[i] += c;
 }
 
@@ -1100,7 +1108,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
 // frag:697 (fp32 history) and the plain sum for the `nframes` samples of a batch, in frame order.
 __global__ __launch_bounds__(BLOCK) void k_accumulate_batch(const float *__restrict__ cur, float *__restrict__ sum,
                                                             float *__restrict__ mean, const size_t nfloats,
-                                                            const int firstLoopNum, const int nframes) {
+                                                            const int firstLoopNum, const int nframes, const int history8) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nfloats) return;
     float m = mean[i], s = sum[i];
@@ -1110,6 +1118,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate_batch(const float *__restr
         const float wa = 1.0f / n, wb = (float)(loopNum - 1) / n;
         const float c = cur[(size_t)f * nfloats + i];
         m = rtm::madd(wa, c, wb * m);
+        if (history8) m = store_unorm8(m);
         s += c;
     }
     mean[i] = m;
@@ -1335,6 +1344,7 @@ int rt_default_options(RtOptions *out) {
     out->cull = 1;
     out->count_work = 0;
     out->accel = 1;
+    out->history8 = 0;
     return RT_OK;
 }
 
@@ -1578,7 +1588,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
         if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
         HIP_TRY(ctx, hipEventRecord(e0, st));
-#define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSum, ctx->dMean, ctx->dCounters)
+#define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters)
         if (cull) { if (cnt) LAUNCH_MEGA(true, true); else LAUNCH_MEGA(true, false); }
         else { if (cnt) LAUNCH_MEGA(false, true); else LAUNCH_MEGA(false, false); }
 #undef LAUNCH_MEGA
@@ -1632,7 +1642,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             HIP_TRY(ctx, hipEventRecord(e1, st));
             ctx->pendingEvents.emplace_back(e0, e1);
             hipLaunchKernelGGL(k_accumulate_batch, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCurBatch, ctx->dSum, ctx->dMean, nfloats,
-                               B.firstLoopNum, B.nframes);
+                               B.firstLoopNum, B.nframes, ctx->opt.history8);
             HIP_TRY(ctx, hipGetLastError());
         }
         ctx->frames += (uint64_t)count;
@@ -1673,7 +1683,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
                                ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
         }
         hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum,
-                           counts, F.maxBounces, ctx->dCounters);
+                           counts, F.maxBounces, ctx->opt.history8, ctx->dCounters);
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->frames += (uint64_t)count;

@@ -134,6 +134,107 @@ int rt_camera_default(RtCamera *out, int width, int height) {
     return RT_OK;
 }
 
+// ---- class Camera (Camera.h:16-139), field for field
+
+static void rig_corner(RtCameraRig *r) {                            // Camera.h:43,57,92,107
+    for (int c = 0; c < 3; c++)
+        r->LeftBottomCorner[c] = r->cameraFront[c] - r->halfW * r->cameraRight[c] - r->halfH * r->cameraUp[c];
+}
+
+int rt_camera_rig_update_vectors(RtCameraRig *r) {
+    if (!r) { rt::set_global_error("rt_camera_rig_update_vectors: null pointer"); return RT_E_INVALID; }
+    r->cameraFront[0] = std::cos(radians(r->Yaw)) * std::cos(radians(r->Pitch));
+    r->cameraFront[1] = std::sin(radians(r->Pitch));
+    r->cameraFront[2] = std::sin(radians(r->Yaw)) * std::cos(radians(r->Pitch));
+    normalize3(r->cameraFront);
+    cross3(r->cameraFront, r->worldUp, r->cameraRight); normalize3(r->cameraRight);
+    cross3(r->cameraRight, r->cameraFront, r->cameraUp); normalize3(r->cameraUp);
+    rig_corner(r);
+    r->LoopNum = 0;
+    return RT_OK;
+}
+
+int rt_camera_rig_init(RtCameraRig *r, int width, int height) {
+    if (!r || width <= 0 || height <= 0) { rt::set_global_error("rt_camera_rig_init: bad argument"); return RT_E_INVALID; }
+    std::memset(r, 0, sizeof *r);
+    r->LoopNum = 0;
+    r->Yaw = -90.0f; r->Pitch = 0.0f; r->fov = 45.0f;
+    r->firstMouse = 1;
+    r->cameraPos[0] = 0.0f; r->cameraPos[1] = 2.0f; r->cameraPos[2] = 5.0f;
+    r->worldUp[0] = 0.0f; r->worldUp[1] = 1.0f; r->worldUp[2] = 0.0f;
+    r->ScreenRatio = (float)width / (float)height;
+    r->halfH = std::tan(radians(r->fov));
+    r->halfW = r->halfH * r->ScreenRatio;
+    r->cameraSpeed = 1.0f;
+    return rt_camera_rig_update_vectors(r);
+}
+
+int rt_camera_rig_update_fov(RtCameraRig *r, float offset) {
+    if (!r) { rt::set_global_error("rt_camera_rig_update_fov: null pointer"); return RT_E_INVALID; }
+    r->fov -= offset;
+    if (r->fov < 1.0f) r->fov = 1.0f;
+    if (r->fov > 45.0f) r->fov = 45.0f;
+    r->halfH = std::tan(radians(r->fov));
+    r->halfW = r->halfH * r->ScreenRatio;
+    rig_corner(r);
+    r->LoopNum = 0;
+    return RT_OK;
+}
+
+int rt_camera_rig_update_front(RtCameraRig *r, float xpos, float ypos) {
+    if (!r) { rt::set_global_error("rt_camera_rig_update_front: null pointer"); return RT_E_INVALID; }
+    if (r->firstMouse) { r->lastX = xpos; r->lastY = ypos; r->firstMouse = 0; }
+    float xoffset = xpos - r->lastX, yoffset = r->lastY - ypos;
+    r->lastX = xpos; r->lastY = ypos;
+    const float sensitivity = 0.03f;
+    xoffset *= sensitivity; yoffset *= sensitivity;
+    r->Yaw += xoffset; r->Pitch += yoffset;
+    if (r->Pitch > 89.0f) r->Pitch = 89.0f;
+    if (r->Pitch < -89.0f) r->Pitch = -89.0f;
+    return rt_camera_rig_update_vectors(r);
+}
+
+int rt_camera_rig_update_screen_ratio(RtCameraRig *r, int width, int height) {
+    if (!r || width <= 0 || height <= 0) { rt::set_global_error("rt_camera_rig_update_screen_ratio: bad argument"); return RT_E_INVALID; }
+    r->ScreenRatio = (float)width / (float)height;
+    r->halfW = r->halfH * r->ScreenRatio;
+    rig_corner(r);
+    r->LoopNum = 0;
+    return RT_OK;
+}
+
+int rt_camera_rig_process_keyboard(RtCameraRig *r, int direction, float delta_time) {
+    if (!r || direction < RT_CAMERA_FORWARD || direction > RT_CAMERA_RIGHT) { rt::set_global_error("rt_camera_rig_process_keyboard: bad argument"); return RT_E_INVALID; }
+    const float velocity = r->cameraSpeed * delta_time;
+    for (int c = 0; c < 3; c++) {
+        if (direction == RT_CAMERA_FORWARD) r->cameraPos[c] += r->cameraFront[c] * velocity;
+        if (direction == RT_CAMERA_BACKWARD) r->cameraPos[c] -= r->cameraFront[c] * velocity;
+        if (direction == RT_CAMERA_LEFT) r->cameraPos[c] -= r->cameraRight[c] * velocity;
+        if (direction == RT_CAMERA_RIGHT) r->cameraPos[c] += r->cameraRight[c] * velocity;
+    }
+    rig_corner(r);
+    r->LoopNum = 0;
+    return RT_OK;
+}
+
+int rt_camera_rig_loop_increase(RtCameraRig *r) {
+    if (!r) { rt::set_global_error("rt_camera_rig_loop_increase: null pointer"); return RT_E_INVALID; }
+    r->LoopNum++;
+    return RT_OK;
+}
+
+int rt_camera_rig_uniforms(const RtCameraRig *r, RtCamera *out) {
+    if (!r || !out) { rt::set_global_error("rt_camera_rig_uniforms: null pointer"); return RT_E_INVALID; }
+    for (int c = 0; c < 3; c++) {
+        out->camPos[c] = r->cameraPos[c]; out->front[c] = r->cameraFront[c];
+        out->right[c] = r->cameraRight[c]; out->up[c] = r->cameraUp[c];
+        out->leftbottom[c] = r->LeftBottomCorner[c];
+    }
+    out->halfH = r->halfH; out->halfW = r->halfW;
+    out->LoopNum = r->LoopNum;
+    return RT_OK;
+}
+
 float rt_rand_origin(uint32_t *state) {
     // xorshift32 (Marsaglia 13/17/5); the top 24 bits give u in [0,1) exactly in fp32.
     uint32_t x = *state ? *state : 0x9E3779B9u;

@@ -2,7 +2,7 @@
 //
 //   rt_render [--demo | --obj FILE SX SY SZ TX TY TZ ... | --synthetic KIND LEVEL COPIES]
 //             [--sphere CX CY CZ R AR AG AB DIFFUSE_RATE MIRROR_RATE] [--size W H] [--spp N]
-//             [--bounces B] [--seed S] [--camera PX PY PZ YAW PITCH FOV] [--exact] [--megakernel | --wavefront]
+//             [--bounces B] [--seed S] [--camera PX PY PZ YAW PITCH FOV] [--exact] [--megakernel | --wavefront] [--history8]
 //             [--out image.pfm] [--ppm image.ppm]
 //
 // Loads the scene (Model + Scene::pushModel), builds the BVH in the reference's node order
@@ -29,7 +29,7 @@ static int die(const char *what, RtContext *ctx) {
 int main(int argc, char **argv) {
     int W = 1200, H = 800, spp = 16, bounces = 4;     // SCR_WIDTH/SCR_HEIGHT of main.cpp:29-30
     uint32_t seed = 20221003u;
-    bool exact = false, mega = false, wavefront = false, customCam = false, haveGeometry = false;
+    bool exact = false, mega = false, wavefront = false, history8 = false, customCam = false, haveGeometry = false;
     float camArgs[6] = {0, 2, 5, -90, 0, 45};
     std::string outPfm, outPpm;
     RtScene *scene = nullptr;
@@ -65,6 +65,7 @@ int main(int argc, char **argv) {
         else if (a == "--exact") exact = true;
         else if (a == "--megakernel") mega = true;
         else if (a == "--wavefront") wavefront = true;
+        else if (a == "--history8") history8 = true;
         else if (a == "--out") { need(1); outPfm = argv[++i]; }
         else if (a == "--ppm") { need(1); outPpm = argv[++i]; }
         else { std::fprintf(stderr, "rt_render: unknown option %s\n", a.c_str()); return 2; }
@@ -97,6 +98,7 @@ int main(int argc, char **argv) {
     rt_default_options(&opt);
     opt.max_bounces = bounces;
     opt.accel = exact ? 0 : 1;
+    opt.history8 = history8 ? 1 : 0;      // the reference keeps its running mean in an 8-bit texture (RT_Screen.h:61)
     opt.pipeline = mega ? RT_PIPELINE_MEGAKERNEL : (wavefront ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_PERSISTENT);
     if (rt_set_options(ctx, &opt) != RT_OK) return die("rt_set_options", ctx);
 

@@ -29,8 +29,8 @@ def test_header_compiles_as_c_and_struct_sizes_match():
     prog = r'''
 #include "rt_amd.h"
 #include <stdio.h>
-int main(void) { printf("%zu %zu %zu %zu %zu %zu\n", sizeof(RtTriangle), sizeof(RtLinearBVHNode), sizeof(RtSphere),
-                        sizeof(RtCamera), sizeof(RtStats), sizeof(RtOptions)); return 0; }
+int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(RtTriangle), sizeof(RtLinearBVHNode), sizeof(RtSphere),
+                        sizeof(RtCamera), sizeof(RtStats), sizeof(RtOptions), sizeof(RtCameraRig)); return 0; }
 '''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -38,8 +38,8 @@ int main(void) { printf("%zu %zu %zu %zu %zu %zu\n", sizeof(RtTriangle), sizeof(
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                                os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    assert [int(x) for x in out] == [144, 36, 40, 72, 48, 20]
-    assert C.sizeof(rt.RtStats) == 48 and C.sizeof(rt.RtOptions) == 20
+    assert [int(x) for x in out] == [144, 36, 40, 72, 48, 24, C.sizeof(rt.RtCameraRig)]
+    assert C.sizeof(rt.RtStats) == 48 and C.sizeof(rt.RtOptions) == 24 and C.sizeof(rt.RtCameraRig) == 116
 
 
 def test_no_oracle_in_the_product():
@@ -68,7 +68,7 @@ def test_host_side_argument_checks():
     assert rt.lib.rt_version().startswith(b"rt_amd")
     o = rt.RtOptions()
     assert rt.lib.rt_default_options(C.byref(o)) == 0
-    assert (o.max_bounces, o.pipeline, o.cull, o.count_work, o.accel) == (4, rt.PIPELINE_PERSISTENT, 1, 0, 1)
+    assert (o.max_bounces, o.pipeline, o.cull, o.count_work, o.accel, o.history8) == (4, rt.PIPELINE_PERSISTENT, 1, 0, 1, 0)
 
 
 def test_create_without_gpu_fails_loudly():

@@ -152,6 +152,40 @@ def test_persistent_pipeline_frame_batches():
     assert res[rt.PIPELINE_PERSISTENT][2] == res[rt.PIPELINE_WAVEFRONT][2]
 
 
+@pytest.mark.parametrize("pipeline", [rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL])
+def test_eight_bit_history_emulation(pipeline):
+    """history8: after every frame the running mean is what an 8-bit GL_RGB attachment keeps of
+    it (RT_Screen.h:61).  The oracle is fed its own quantised history frame by frame."""
+    W, H = 64, 40
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(4, 9)
+    osc = _oracle_for(tris, nodes, W, H, sc.spheres())
+    hist = np.zeros((H, W, 3), dtype=np.float32)
+    for k in range(len(ro)):
+        out, _, _ = osc.render_frame(cam, k + 1, float(ro[k]), hist)
+        c = np.where(out > 0, np.minimum(out, np.float32(1.0)), np.float32(0.0)).astype(np.float32)   # NaN -> 0
+        hist = (np.floor(c * np.float32(255.0) + np.float32(0.5)) / np.float32(255.0)).astype(np.float32)
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    r.set_spheres(sc.spheres())
+    r.set_camera(cam)
+    r.set_options(pipeline=pipeline, history8=True)
+    r.render(1, ro[:4]); r.render(5, ro[4:])
+    got = r.read_mean()
+    assert np.array_equal(got, hist)
+    levels = np.unique(np.round(got.astype(np.float64) * 255.0))
+    assert levels.min() >= 0 and levels.max() <= 255
+    # the fp32 image of the same frames differs: samples reach 4*pi, and the 8-bit history clamps
+    # every frame's mean to 1 (a property of the reference's storage, not an error bound)
+    r.set_options(pipeline=pipeline, history8=False)
+    r.reset()
+    r.render(1, ro)
+    ref = r.read_mean()
+    assert not np.array_equal(ref, got)
+
+
 def test_golden_vectors(golden_dir):
     """Committed expected values (made by the oracle from the reference's scene files)."""
     import os
