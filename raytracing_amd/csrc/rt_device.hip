@@ -1009,6 +1009,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                     }
                 }
             }
+            bool startRay = false;
+            vec3 nextO = rtm::mk(0.0f, 0.0f, 0.0f), nextD = rtm::mk(0.0f, 0.0f, 0.0f);
             if (fin) {
                 cRays++;
                 if (COUNT && tv.best != REF_NONE) cHit++;
@@ -1023,16 +1025,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
-                    if constexpr (FAST) tv.begin(S, stack, BLOCK, p.o, p.d, cNode); else tv.begin(S, p.o, p.d, cNode);
+                    nextO = p.o; nextD = p.d; startRay = true;
                 } else {
                     float *dst = cur + (size_t)slot * frameFloats + ((size_t)py * (size_t)F.width + px) * 3;
                     dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
                     have = false;
                 }
             }
-            // new paths for the idle lanes (a second round when the wave's chunk ran out half way)
+            // items for the idle lanes (a second round when the wave's chunk ran out half way)
+            uint32_t item = 0xFFFFFFFFu;
             for (int round = 0; round < 2; round++) {
-                const unsigned long long freeMask = __ballot(!have);
+                const unsigned long long freeMask = __ballot(!have && item == 0xFFFFFFFFu);
                 if (freeMask == 0ull || (exhausted && cNext >= cEnd)) break;
                 if (cNext >= cEnd) {
                     uint32_t base = 0;
@@ -1050,21 +1053,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                 const uint32_t left = cEnd - cNext;
                 const uint32_t give = nFree < left ? nFree : left;
                 const uint32_t rank = (uint32_t)__popcll(freeMask & below);
-                if (!have && rank < give) {
-                    const uint32_t idx = cNext + rank;
-                    const uint32_t slot = idx / framePix, rem = idx - slot * framePix;
-                    uint32_t px, py;
-                    if (tile_pixel((int)(rem >> 6), (int)(rem & 63u), F.width, F.height, px, py)) {
-                        Path p; float uvx, uvy;
-                        generate_path(F, B.randOrigin[slot], px, py, p, uvx, uvy);
-                        thr = p.thr; seed = p.seed; bounce = 0;
-                        pix = px | (py << 14) | (slot << 28);
-                        if constexpr (FAST) tv.begin(S, stack, BLOCK, p.o, p.d, cNode); else tv.begin(S, p.o, p.d, cNode);
-                        have = true;
-                    }
-                }
+                if (!have && item == 0xFFFFFFFFu && rank < give) item = cNext + rank;
                 cNext += give;
                 if (give == nFree) break;
+            }
+            if (item != 0xFFFFFFFFu) {
+                const uint32_t slot = item / framePix, rem = item - slot * framePix;
+                uint32_t px, py;
+                if (tile_pixel((int)(rem >> 6), (int)(rem & 63u), F.width, F.height, px, py)) {
+                    Path p; float uvx, uvy;
+                    generate_path(F, B.randOrigin[slot], px, py, p, uvx, uvy);
+                    thr = p.thr; seed = p.seed; bounce = 0;
+                    pix = px | (py << 14) | (slot << 28);
+                    nextO = p.o; nextD = p.d; startRay = true;
+                    have = true;
+                }
+            }
+            // continued and new paths start their rays together
+            if (startRay) {
+                if constexpr (FAST) tv.begin(S, stack, BLOCK, nextO, nextD, cNode); else tv.begin(S, nextO, nextD, cNode);
             }
             if (__ballot(have) == 0ull) {
                 if (exhausted && cNext >= cEnd) break;
