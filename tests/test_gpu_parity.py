@@ -186,6 +186,71 @@ def test_eight_bit_history_emulation(pipeline):
     assert not np.array_equal(ref, got)
 
 
+def _render_all_pipelines(tris, nodes, cam, ro, W, H, spheres=None, bounces=4):
+    out = {}
+    for name, pipeline, accel in (("paths", rt.PIPELINE_PERSISTENT, True), ("paths_ref_order", rt.PIPELINE_PERSISTENT, False),
+                                  ("wavefront", rt.PIPELINE_WAVEFRONT, True), ("mega", rt.PIPELINE_MEGAKERNEL, False)):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        if spheres is not None:
+            r.set_spheres(spheres)
+        r.set_camera(cam)
+        r.set_options(max_bounces=bounces, pipeline=pipeline, accel=accel)
+        r.render(1, ro)
+        out[name] = (r.read_mean(), r.stats()["rays"])
+        r.close()
+    return out
+
+
+def _same_image(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+@pytest.mark.parametrize("case", ["one_triangle", "two_triangles", "degenerate", "camera_inside_light", "all_miss", "far_scene"])
+def test_small_and_awkward_scenes(case):
+    """Scenes at the edges of the data structures: a root that is a leaf, zero-area and
+    repeated-vertex triangles, a camera inside an emissive box, nothing in view, coordinates
+    around 1e4 (the index boxes grow with the scene scale)."""
+    W, H = 48, 32
+    rng = np.random.default_rng(len(case))
+    if case == "one_triangle":
+        t = scenes.random_triangles(1, 3, extent=0.5, size=3.0)
+        t["v"][0] = [[-4, -3, -6], [4, -3, -6], [0, 6, -6]]
+    elif case == "two_triangles":
+        t = scenes.random_triangles(2, 4, extent=0.5, size=3.0)
+        t["v"][0] = [[-4, -3, -6], [4, -3, -6], [0, 6, -6]]
+        t["v"][1] = [[-4, -3, -5], [4, -3, -5], [0, 6, -5]]
+    elif case == "degenerate":
+        t = scenes.random_triangles(200, 5, extent=3.0, size=1.5)
+        t["v"][:20, 1] = t["v"][:20, 0]                     # repeated vertex: zero area
+        t["v"][20:40, 2] = (t["v"][20:40, 0] + t["v"][20:40, 1]) * np.float32(0.5)     # collinear
+        t["v"][40:50] = t["v"][40:50, :1]                   # a point
+    elif case == "camera_inside_light":
+        t = scenes.random_triangles(60, 6, extent=6.0, size=6.0)
+        t["ka"][:] = (0.7, 0.8, 0.9)
+    elif case == "all_miss":
+        t = scenes.random_triangles(50, 7, extent=2.0, size=1.0)
+        t["v"][:, :, 2] += 40.0                             # behind the camera
+    else:
+        t = scenes.random_triangles(500, 8, extent=4.0, size=1.5)
+        t["v"] = (t["v"] * np.float32(100.0) + np.float32(10000.0)).astype(np.float32)
+    tris, nodes = rt.bvh_build(t)
+    if case == "far_scene":
+        cam = rt.camera_from_angles((10000.0, 10000.0, 11500.0), -90.0, 0.0, 45.0, W, H)
+    else:
+        cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(31, 3)
+    want, st = _oracle_for(tris, nodes, W, H, None).render(cam, 1, ro, want_stats=True)
+    res = _render_all_pipelines(tris, nodes, cam, ro, W, H)
+    for name, (img, rays) in res.items():
+        assert _same_image(img, want), (case, name)
+        assert rays == st["rays"], (case, name)
+    if case == "all_miss":
+        assert not want.any()
+    if case in ("one_triangle", "camera_inside_light", "far_scene"):
+        assert np.nan_to_num(want).max() > 0 or case == "one_triangle"
+
+
 def test_golden_vectors(golden_dir):
     """Committed expected values (made by the oracle from the reference's scene files)."""
     import os
