@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_amd.so")
 SOURCES = ["rt_device.hip", "rt_bvh.cpp", "rt_host.cpp", "rt_scene.cpp", "rt_accel.cpp"]
 MAIN = "rt_main.cpp"
-HEADERS = ["rt_internal.h", "rt_kernels.h", "rt_math.h", "rt_accel.h", os.path.join("..", "..", "include", "rt_amd.h")]
+HEADERS = ["rt_internal.h", "rt_kernels.h", "rt_math.h", "rt_accel.h", "rt_traverse.h", "rt_shade.h", os.path.join("..", "..", "include", "rt_amd.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

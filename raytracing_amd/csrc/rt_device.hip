@@ -14,13 +14,11 @@
 #include "rt_accel.h"
 #include "rt_internal.h"
 #include "rt_kernels.h"
+#include "rt_shade.h"
+#include "rt_traverse.h"
 
 using namespace rtd;
 using rtm::vec3;
-
-// Sobol direction numbers (uniform uint V[512], frag:81) live in constant memory: every lane
-// of a wave reads the same word, which the scalar unit serves.
-__constant__ uint32_t c_sobolV[RT_SOBOL_WORDS];
 
 namespace {
 
@@ -31,554 +29,6 @@ constexpr int BLOCK = 256;          // 4 waves
 // bounce.  Wave-sized chunk c of a producer goes to shard c % NSHARD.
 constexpr int NSHARD = 16;
 constexpr int CTL_STRIDE = 32;      // words between counters (128 bytes)
-constexpr float HIT_MIN_INIT = 100000.0f;   // frag:633,689
-constexpr int FAST_QUEUE_ENTRIES = 6;        // FastTrav::PEND_MAX: LDS entries per lane ahead of the deferred nodes
-
-// ------------------------------------------------------------------ small device helpers
-
-__device__ __forceinline__ float rand01(uint32_t &wseed) {     // frag:36-47
-    wseed = rtm::wang_step(wseed);
-    return (float)wseed * (1.0f / 4294967296.0f);
-}
-
-// frag:84-104 for one bounce: dims 2b and 2b+1 of frame `loopNum`.  loopNum and b are wave
-// uniform, so this runs on the scalar unit out of constant memory.
-__device__ __forceinline__ void sobol_pair(uint32_t loopNum, uint32_t b, float &u, float &v) {
-    uint32_t g = loopNum ^ (loopNum >> 1);
-    uint32_t r0 = 0u, r1 = 0u;
-    const uint32_t base = b * 64u;
-    for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
-        if (g & 1u) {
-            r0 ^= c_sobolV[base + j];
-            r1 ^= c_sobolV[base + 32u + j];
-        }
-    u = (float)r0 * (1.0f / 4294967296.0f);
-    v = (float)r1 * (1.0f / 4294967296.0f);
-}
-
-// frag:59-77
-__device__ __forceinline__ void cranley_patterson(float uvx, float uvy, int width, int height, float &px, float &py) {
-    const uint32_t X = (uint32_t)(rtm::madd(rtm::madd(uvx, 2.0f, -1.0f), 0.5f, 0.5f) * (float)width);
-    const uint32_t Y = (uint32_t)(rtm::madd(rtm::madd(uvy, 2.0f, -1.0f), 0.5f, 0.5f) * (float)height);
-    uint32_t pseed = (X * 1973u + Y * 9277u + (uint32_t)(114514 / 1919) * 26699u) | 1u;
-    pseed = rtm::wang_step(pseed);
-    const float u = (float)pseed / 4294967296.0f;
-    pseed = rtm::wang_step(pseed);
-    const float v = (float)pseed / 4294967296.0f;
-    float x = px + u;
-    if (x > 1.0f) x -= 1.0f;
-    if (x < 0.0f) x += 1.0f;
-    float y = py + v;
-    if (y > 1.0f) y -= 1.0f;
-    if (y < 0.0f) y += 1.0f;
-    px = x; py = y;
-}
-
-// IntersectBound, frag:309-331, evaluated without early exits (the values computed after a
-// failed test are unused, so the outcome is the same).  near[] receives the three entry
-// distances for the conservative culling bound.
-__device__ __forceinline__ bool slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                          const vec3 o, const vec3 inv, bool nx, bool ny, bool nz,
-                                          float &nearx, float &neary, float &nearz) {
-    float tMin = ((nx ? mxx : mnx) - o.x) * inv.x;
-    float tMax = ((nx ? mnx : mxx) - o.x) * inv.x;
-    const float tyMin = ((ny ? mxy : mny) - o.y) * inv.y;
-    const float tyMax = ((ny ? mny : mxy) - o.y) * inv.y;
-    nearx = tMin; neary = tyMin;
-    const bool fail1 = (tMin > tyMax) || (tyMin > tMax);
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
-    const float tzMin = ((nz ? mxz : mnz) - o.z) * inv.z;
-    const float tzMax = ((nz ? mnz : mxz) - o.z) * inv.z;
-    nearz = tzMin;
-    const bool fail2 = (tMin > tzMax) || (tzMin > tMax);
-    if (tzMax < tMax) tMax = tzMax;
-    return !fail1 && !fail2 && (tMax > 0.0f);
-}
-
-// hitTriangle, frag:255-278, with N and D taken from the triangle record.
-__device__ __forceinline__ float triangle_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
-                                               const vec3 o, const vec3 d) {
-    const vec3 v0 = rtm::mk(q0.x, q0.y, q0.z);
-    const vec3 v1 = rtm::mk(q0.w, q1.x, q1.y);
-    const vec3 v2 = rtm::mk(q1.z, q1.w, q2.x);
-    const vec3 N = rtm::mk(q2.y, q2.z, q2.w);
-    const float D = q3.x;
-    const float nd = rtm::dot(N, d);
-    if (nd == 0.0f) return -1.0f;
-    const float t = -(rtm::dot(N, o) + D) / nd;
-    if (t < 0.0f) return -1.0f;
-    const vec3 pHit = rtm::along(o, t, d);
-    if (rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pHit, v0))) < 0.0f) return -1.0f;
-    if (rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pHit, v1))) < 0.0f) return -1.0f;
-    if (rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pHit, v2))) < 0.0f) return -1.0f;
-    return t - 0.00001f;
-}
-
-// The traversal loop of hitBVH, frag:380-421, as a per-lane state machine.  It visits children
-// in the reference's order (near child by dirIsNeg[axis], far child deferred on a LIFO stack)
-// and keeps the closest hit with the same strict comparison, so ties resolve as in the
-// reference.  `cur` is the next thing to process: an interior node index, LEAF_BIT|triangle,
-// or REF_NONE when the ray is finished.
-// stack: this lane's LDS column, entry i at stack[i*stride].
-// CULL: additionally skip a box when a lower bound of its entry distance, computed against
-// the box grown by eps, lies beyond the closest hit so far; no triangle in such a box can
-// pass `dis_t < ray.hitMin` (frag:396), so the result is unchanged.
-template <bool CULL, bool COUNT>
-struct Trav {
-    vec3 o, d, inv;
-    float ex, ey, ez, hitCull;
-    float hitMin;
-    uint32_t best;
-    uint32_t cur;
-    int sp;
-    bool nx, ny, nz;
-
-    __device__ __forceinline__ void begin(const SceneD &S, const vec3 o_, const vec3 d_, uint32_t &nNode) {
-        o = o_; d = d_;
-        hitMin = HIT_MIN_INIT;
-        best = REF_NONE;
-        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);         // frag:376
-        nx = inv.x < 0.0f; ny = inv.y < 0.0f; nz = inv.z < 0.0f;    // frag:378
-        ex = ey = ez = hitCull = 0.0f;
-        if (CULL) {
-            const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-            const float eps = rtm::madd(oM, 1.0f / 1024.0f, S.cullEps);
-            ex = eps * fabsf(inv.x); ey = eps * fabsf(inv.y); ez = eps * fabsf(inv.z);
-            hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-        }
-        sp = 0;
-        cur = S.rootRef;
-        if (cur != REF_NONE) {
-            float a, b, c;
-            const bool pass = slab_test(S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2],
-                                        o, inv, nx, ny, nz, a, b, c);
-            if (COUNT) nNode++;
-            if (!pass) cur = REF_NONE;
-        }
-    }
-
-    __device__ __forceinline__ bool at_interior() const { return (int32_t)cur >= 0; }          // not LEAF, not NONE
-    __device__ __forceinline__ bool at_leaf() const { return (cur & LEAF_BIT) && cur != REF_NONE; }
-    __device__ __forceinline__ bool done() const { return cur == REF_NONE; }
-
-    __device__ __forceinline__ void pop(const uint32_t *stack, const int stride) {
-        cur = REF_NONE;
-        if (sp > 0) cur = stack[(--sp) * stride];
-    }
-
-    // cur is an interior node: test both children, descend / defer / pop (frag:386-420)
-    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t &nNode) {
-        const float4 *rec = S.nodes + (size_t)cur * 4;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        float lnx, lny, lnz, rnx, rny, rnz;
-        bool passL = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, lnx, lny, lnz);
-        bool passR = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, nx, ny, nz, rnx, rny, rnz);
-        if (COUNT) nNode += 2;
-        if (CULL) {
-            const float lb = fmaxf(lnx - ex, fmaxf(lny - ey, lnz - ez));
-            const float rb = fmaxf(rnx - ex, fmaxf(rny - ey, rnz - ez));
-            if (lb > hitCull) passL = false;
-            if (rb > hitCull) passR = false;
-        }
-        const uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
-        const bool negAxis = (axis == 0u) ? nx : ((axis == 1u) ? ny : nz);      // frag:407
-        const uint32_t nearRef = negAxis ? right : left;
-        const uint32_t farRef = negAxis ? left : right;
-        const bool nearPass = negAxis ? passR : passL;
-        const bool farPass = negAxis ? passL : passR;
-        if (nearPass) {
-            cur = nearRef;
-            if (farPass) stack[(sp++) * stride] = farRef;
-        } else if (farPass) {
-            cur = farRef;
-        } else {
-            pop(stack, stride);
-        }
-    }
-
-    // cur is a leaf: test its triangle, keep it if closer (frag:390-403), then pop
-    __device__ __forceinline__ void leaf_step(const SceneD &S, const uint32_t *stack, const int stride, uint32_t &nTri) {
-        const uint32_t ti = cur & ~LEAF_BIT;
-        const float4 *rec = S.tris + (size_t)ti * 4;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        const float dis = triangle_test(q0, q1, q2, q3, o, d);
-        if (COUNT) nTri++;
-        if (dis > 0.0f && dis < hitMin) {           // frag:396
-            hitMin = dis;
-            best = ti;
-            if (CULL) hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-        }
-        pop(stack, stride);
-    }
-};
-
-// Every lane of a wave that is still working is either at an interior node or at a leaf.
-// Measured on MI355X: making lanes wait at a leaf so that triangle tests run in batches
-// (while-while traversal) is slower at every batch size (1.22 -> 0.66 Grays/s from batch 1 to
-// 64 on the 1.31M-triangle scene); the cost is per wave iteration, not per issued instruction.
-
-template <bool CULL, bool COUNT>
-__device__ __forceinline__ void wave_advance(Trav<CULL, COUNT> &tv, const SceneD &S, uint32_t *stack, const int stride,
-                                             uint32_t &nNode, uint32_t &nTri, unsigned long long mInterior,
-                                             unsigned long long mLeaf) {
-    // every working lane advances by one step per iteration
-    if (tv.at_interior()) tv.node_step(S, stack, stride, nNode);
-    else if (tv.at_leaf()) tv.leaf_step(S, stack, stride, nTri);
-}
-
-// Runs the rays of the calling lanes to completion (all lanes leave together).
-template <bool CULL, bool COUNT>
-__device__ __forceinline__ void closest_triangle(const SceneD &S, const vec3 o, const vec3 d,
-                                                 uint32_t *stack, const int stride,
-                                                 float &tOut, uint32_t &triOut,
-                                                 uint32_t &nNode, uint32_t &nTri) {
-    Trav<CULL, COUNT> tv;
-    tv.begin(S, o, d, nNode);
-    while (true) {
-        const unsigned long long mI = __ballot(tv.at_interior());
-        const unsigned long long mL = __ballot(tv.at_leaf());
-        if ((mI | mL) == 0ull) break;
-        wave_advance(tv, S, stack, stride, nNode, nTri, mI, mL);
-    }
-    tOut = tv.hitMin;
-    triOut = tv.best;
-}
-
-// ---------------------------------------------------------------- search index traversal
-
-__device__ __forceinline__ bool finite3(const vec3 v) {
-    return (fabsf(v.x) < INFINITY) && (fabsf(v.y) < INFINITY) && (fabsf(v.z) < INFINITY);
-}
-
-//
-// Finds the closest triangle that hitTriangle accepts, through the SAH index.  The index boxes
-// are grown (rt_accel.cpp), the box test below treats NaN as "inside", and a box is only
-// skipped when it starts beyond the closest hit so far by a margin, so no triangle that could
-// be accepted at a distance <= the final one is missed.  `tie` reports that two different
-// triangles were accepted at exactly the final distance (the reference keeps whichever it
-// meets first, which this search cannot tell).
-template <bool COUNT>
-struct FastTrav {
-    vec3 o, d, inv;
-    float hitMin, hitCull;
-    uint32_t best, cur;         // cur: interior node of the index, or REF_NONE when nothing is left
-    int sp;
-    bool tie;
-    // Triangles met but not yet tested.  Leaves of the index hold one triangle each and are
-    // named by their parent, so a node step never has to stop at a leaf: it queues the
-    // triangle and goes on.  The wave tests queued triangles together (one per lane per
-    // pass); testing them one lane at a time costs a full pass of the long triangle code at a
-    // few percent lane utilisation.  The search keeps every candidate whatever the order of
-    // the tests.  The queue is the first PEND_MAX entries of the lane's LDS column, the
-    // deferred nodes follow it.
-    int npend;
-
-    static constexpr int PEND_MAX = FAST_QUEUE_ENTRIES;     // a node step may queue up to 4 triangles
-
-    // rays this search may be used for: finite 1/d and an origin within the range the growth
-    // of the index boxes was sized for
-    __device__ __forceinline__ bool usable(const SceneD &S) const {
-        const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-        return finite3(inv) && (oM <= S.originLimit);
-    }
-    __device__ __forceinline__ void queue_triangle(uint32_t *col, const int stride, uint32_t ti) {
-        col[npend * stride] = ti;
-        npend++;
-    }
-    __device__ __forceinline__ uint32_t unqueue_triangle(const uint32_t *col, const int stride) {
-        npend--;
-        return col[npend * stride];
-    }
-    // deferred nodes: LDS column of this lane first, global overflow beyond S.aldsEntries
-    __device__ __forceinline__ void push(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t v) {
-        if (sp < S.aldsEntries) col[(PEND_MAX + sp) * stride] = v;
-        else ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride] = v;
-        sp++;
-    }
-    __device__ __forceinline__ uint32_t pop(const SceneD &S, const uint32_t *col, const int stride, const uint32_t *ovf) {
-        sp--;
-        return (sp < S.aldsEntries) ? col[(PEND_MAX + sp) * stride] : ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride];
-    }
-
-    __device__ __forceinline__ void begin(const SceneD &S, uint32_t *col, const int stride, const vec3 o_, const vec3 d_, uint32_t &nNode) {
-        o = o_; d = d_;
-        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        hitMin = HIT_MIN_INIT;
-        hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-        best = REF_NONE; tie = false; sp = 0; npend = 0;
-        // root box (not quantised)
-        const float x0 = (S.arootMin[0] - o.x) * inv.x, x1 = (S.arootMax[0] - o.x) * inv.x;
-        const float y0 = (S.arootMin[1] - o.y) * inv.y, y1 = (S.arootMax[1] - o.y) * inv.y;
-        const float z0 = (S.arootMin[2] - o.z) * inv.z, z1 = (S.arootMax[2] - o.z) * inv.z;
-        const float tn = fmaxf(fminf(x0, x1), fmaxf(fminf(y0, y1), fminf(z0, z1)));
-        const float tf = fminf(fmaxf(x0, x1), fminf(fmaxf(y0, y1), fmaxf(z0, z1)));
-        if (COUNT) nNode++;
-        cur = REF_NONE;
-        // a ray with a zero, NaN or infinite direction component is not searched here at all
-        // (with NaN every box would count as hit); the caller sends it to the exact path
-        if (!(tn > tf) && !(tf < 0.0f) && !(tn > hitCull) && usable(S)) {
-            if (S.arootRef & LEAF_BIT) queue_triangle(col, stride, S.arootRef & ~LEAF_BIT);     // one-triangle scene
-            else cur = S.arootRef;
-        }
-    }
-    __device__ __forceinline__ bool can_step() const { return cur != REF_NONE && npend <= PEND_MAX - 4; }
-    __device__ __forceinline__ bool wants_test() const { return npend > 0 && (cur == REF_NONE || npend > PEND_MAX - 4); }
-    __device__ __forceinline__ bool finished() const { return cur == REF_NONE && npend == 0; }
-
-    // cur is a 4-wide node: decode and test its (up to) four child boxes; leaf children that
-    // are hit are queued, interior children are entered nearest first, the others deferred.
-    // With 1/d finite, t along axis k at quantised coordinate q is q*(scale_k/d_k) + (origin_k - o_k)/d_k.
-    // A child counts as hit unless its box provably is not: max(entry, 0) > min(exit, hitCull)
-    // (a NaN entry counts as 0, a NaN exit as hitCull).
-    __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t &nNode) {
-        const float4 *rec = S.anodes + (size_t)cur * 4;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        const uint32_t exps = __float_as_uint(q0.w);
-        const float Ax = __uint_as_float((exps & 0xFFu) << 23) * inv.x, Bx = (q0.x - o.x) * inv.x;
-        const float Ay = __uint_as_float(((exps >> 8) & 0xFFu) << 23) * inv.y, By = (q0.y - o.y) * inv.y;
-        const float Az = __uint_as_float(((exps >> 16) & 0xFFu) << 23) * inv.z, Bz = (q0.z - o.z) * inv.z;
-        const uint32_t lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
-        const uint32_t hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
-        const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
-        const uint32_t nrx = ngx ? hix : lox, frx = ngx ? lox : hix;
-        const uint32_t nry = ngy ? hiy : loy, fry = ngy ? loy : hiy;
-        const uint32_t nrz = ngz ? hiz : loz, frz = ngz ? loz : hiz;
-        uint32_t r0 = __float_as_uint(q1.x), r1 = __float_as_uint(q1.y), r2 = __float_as_uint(q1.z), r3 = __float_as_uint(q1.w);
-        // per child: clamped entry distance and whether the box is hit
-#define RT_CHILD(sh, k, live, r) \
-        const float k = fmaxf(fmaxf(rtm::madd((float)((nrx >> sh) & 0xFFu), Ax, Bx), fmaxf(rtm::madd((float)((nry >> sh) & 0xFFu), Ay, By), \
-                                    rtm::madd((float)((nrz >> sh) & 0xFFu), Az, Bz))), 0.0f); \
-        const bool live = !(k > fminf(fminf(rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), fminf(rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), \
-                                    rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz))), hitCull)) && (r != REF_NONE);
-        RT_CHILD(0, t0, live0, r0) RT_CHILD(8, t1, live1, r1) RT_CHILD(16, t2, live2, r2) RT_CHILD(24, t3, live3, r3)
-#undef RT_CHILD
-        if (COUNT) nNode += 4;
-        // hit leaf children are queued for the triangle pass
-        if (live0 && (r0 & LEAF_BIT)) queue_triangle(col, stride, r0 & ~LEAF_BIT);
-        if (live1 && (r1 & LEAF_BIT)) queue_triangle(col, stride, r1 & ~LEAF_BIT);
-        if (live2 && (r2 & LEAF_BIT)) queue_triangle(col, stride, r2 & ~LEAF_BIT);
-        if (live3 && (r3 & LEAF_BIT)) queue_triangle(col, stride, r3 & ~LEAF_BIT);
-        // hit interior children, farthest first (the others sort last)
-        const bool in0 = live0 && !(r0 & LEAF_BIT), in1 = live1 && !(r1 & LEAF_BIT);
-        const bool in2 = live2 && !(r2 & LEAF_BIT), in3 = live3 && !(r3 & LEAF_BIT);
-        float k0 = in0 ? t0 : -INFINITY, k1 = in1 ? t1 : -INFINITY, k2 = in2 ? t2 : -INFINITY, k3 = in3 ? t3 : -INFINITY;
-        const int m = (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
-#define RT_CSWAP(ka, ra, kb, rb) { const bool sw = kb > ka; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
-                                   const uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
-        RT_CSWAP(k0, r0, k1, r1) RT_CSWAP(k2, r2, k3, r3) RT_CSWAP(k0, r0, k2, r2) RT_CSWAP(k1, r1, k3, r3) RT_CSWAP(k1, r1, k2, r2)
-#undef RT_CSWAP
-        if (m == 0) {
-            cur = (sp > 0) ? pop(S, col, stride, ovf) : REF_NONE;
-        } else {
-            // r0..r(m-2) are deferred (the nearest of them on top), r(m-1) is entered now
-            if (sp + 3 <= S.aldsEntries) {
-                // room for three: store them all, the ones beyond m-1 lie above the new top
-                uint32_t *dst = col + (PEND_MAX + sp) * stride;
-                dst[0] = r0; dst[stride] = r1; dst[2 * stride] = r2;
-                sp += m - 1;
-            } else {
-                if (m > 1) push(S, col, stride, ovf, r0);
-                if (m > 2) push(S, col, stride, ovf, r1);
-                if (m > 3) push(S, col, stride, ovf, r2);
-            }
-            cur = (m == 1) ? r0 : ((m == 2) ? r1 : ((m == 3) ? r2 : r3));
-        }
-    }
-
-    // tests one queued triangle with the reference's hitTriangle arithmetic
-    __device__ __forceinline__ void test_step(const SceneD &S, const uint32_t *col, const int stride, uint32_t &nTri) {
-        const uint32_t ti = unqueue_triangle(col, stride);
-        const float4 *rec = S.tris + (size_t)ti * 4;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        const float dis = triangle_test(q0, q1, q2, q3, o, d);
-        if (COUNT) nTri++;
-        if (dis > 0.0f) {
-            if (dis < hitMin) {
-                hitMin = dis; best = ti; tie = false;
-                hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
-            } else if (dis == hitMin && ti != best) {
-                tie = true;
-            }
-        }
-    }
-};
-
-// The reference reaches triangle `tri` iff every box on the path from the root to its leaf
-// passes IntersectBound.  Those boxes are nested (each is the exact min/max of the triangles
-// below it), and for a ray with finite 1/d the entry distance (b_near - o)*inv can only
-// decrease and the exit distance only increase when a box grows, because fp32 subtraction and
-// multiplication are monotonic.  IntersectBound passes exactly when every entry distance is
-// <= every other axis' exit distance and all exit distances are > 0, so a pass at the leaf
-// implies a pass at every ancestor: testing the leaf's own box (the min/max of the triangle's
-// vertices, BVH.h:42-54) is enough.
-__device__ __forceinline__ bool verify_reference_reaches(const SceneD &S, const vec3 o, const vec3 inv, uint32_t tri) {
-    const float4 *rec = S.tris + (size_t)tri * 4;
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-    const float mnx = fminf(fminf(q0.x, q0.w), q1.z), mxx = fmaxf(fmaxf(q0.x, q0.w), q1.z);
-    const float mny = fminf(fminf(q0.y, q1.x), q1.w), mxy = fmaxf(fmaxf(q0.y, q1.x), q1.w);
-    const float mnz = fminf(fminf(q0.z, q1.y), q2.x), mxz = fmaxf(fmaxf(q0.z, q1.y), q2.x);
-    float a, b, c;
-    return slab_test(mnx, mny, mnz, mxx, mxy, mxz, o, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f, a, b, c);
-}
-
-struct Path {
-    vec3 o, d, thr;
-    uint32_t seed;
-};
-
-// hitSphere, frag:281-293
-__device__ __forceinline__ float sphere_test(const RtSphere &s, const vec3 o, const vec3 d) {
-    const vec3 oc = rtm::sub(o, rtm::mk(s.center[0], s.center[1], s.center[2]));
-    const float a = rtm::dot(d, d);
-    const float b = 2.0f * rtm::dot(oc, d);
-    const float c = rtm::madd(-s.radius, s.radius, rtm::dot(oc, oc));
-    const float disc = rtm::madd(b, b, -((4.0f * a) * c));
-    if (disc > 0.0f) {
-        const float dis = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
-        return (dis > 0.0f) ? dis : -1.0f;
-    }
-    return -1.0f;
-}
-
-// frag:494-500: tangent and bitangent of a normal
-__host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tangent, vec3 &bitangent) {
-    const vec3 helper = (fabsf(nrm.x) > 0.999f) ? rtm::mk(0.0f, 0.0f, 1.0f) : rtm::mk(1.0f, 0.0f, 0.0f);
-    tangent = rtm::normalize(rtm::cross(nrm, helper));
-    bitangent = rtm::normalize(rtm::cross(nrm, tangent));
-}
-
-// Everything the shader does with a ray after the BVH loop: the rest of hitBVH
-// (frag:457-488), the sphere loop of hitWorld (frag:570-614), the material switch of
-// shading (frag:631-670), the 4*pi scaling (frag:672-673) and the Russian-roulette draw that
-// opens the next iteration (frag:625-630).  sobU/sobV are the frame's Sobol numbers for this
-// bounce (sobol_pair).  Returns true when the path goes on (p holds the next ray); otherwise
-// `sample` is the frame's radiance for the pixel.
-__device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
-                                          int bounce, float sobU, float sobV, float uvx, float uvy, vec3 &sample) {
-    sample = rtm::mk(0.0f, 0.0f, 0.0f);
-    bool hit = false;
-    float hitMin = HIT_MIN_INIT;
-    vec3 pos = rtm::mk(0, 0, 0), nrm = rtm::mk(0, 0, 0), albedo = rtm::mk(0, 0, 0);
-    int material = -1;
-    float refraction = 1.0f;
-    // tangent frame of the hit: taken from the triangle's record, computed for a sphere
-    bool recFrame = false;
-    vec3 tangent = rtm::mk(0, 0, 0), bitangent = rtm::mk(0, 0, 0);
-    if (tri != REF_NONE) {
-        const float4 *m = S.mats + (size_t)tri * 5;
-        const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4];
-        pos = rtm::along(p.o, tTri, p.d);                                       // frag:458
-        nrm = rtm::mk(m2.y, m2.z, m2.w);                                        // frag:296-300, precomputed
-        tangent = rtm::mk(m3.x, m3.y, m3.z);
-        bitangent = rtm::mk(m3.w, m4.x, m4.y);
-        recFrame = true;
-        if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
-        const float temp = rand01(p.seed);                                      // frag:462
-        const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
-        const float ksx = m1.z, ksy = m1.w;
-        if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }             // length(ka) > 0
-        else if (temp < ksx) { material = 1; albedo = kd; }
-        else if (temp < ksy) { material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f); }
-        else { material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f); refraction = 1.5f; }
-        if (tTri > 0.0f && tTri < hitMin) { hitMin = tTri; hit = true; }        // frag:562-565
-    }
-    for (int i = 0; i < F.sphereNum; i++) {                                     // frag:570-614
-        const RtSphere &s = F.sph[i];
-        const float dis = sphere_test(s, p.o, p.d);
-        if (dis > 0.0f && dis < hitMin) {
-            hitMin = dis;
-            hit = true;
-            const vec3 centre = rtm::mk(s.center[0], s.center[1], s.center[2]);
-            const vec3 n0 = rtm::sub(rtm::along(p.o, hitMin, p.d), centre);
-            const bool internal = rtm::dot(n0, p.d) > 0.0f;
-            const float temp = rand01(p.seed);
-            if (temp < s.specularRate) {
-                hitMin -= 0.00001f; material = 1; albedo = rtm::mk(s.albedo[0], s.albedo[1], s.albedo[2]);
-            } else if (temp < s.refractionRate) {
-                hitMin -= 0.00001f; material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f);
-            } else {
-                hitMin += 0.00001f; material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f);
-                refraction = internal ? 1.0f / 1.3f : 1.3f;
-            }
-            pos = rtm::along(p.o, hitMin, p.d);
-            nrm = rtm::sub(pos, centre);
-            recFrame = false;
-        }
-    }
-    if (!hit) return false;         // a miss can never reach a light afterwards (frag:655-672)
-    p.o = pos;
-    p.thr = rtm::mul(p.thr, albedo);                                            // frag:635
-    if (material == 0) {                                                        // frag:642-645
-        sample = rtm::scale(p.thr, 4.0f * 3.1415926f);                          // frag:673
-        return false;
-    }
-    if (material == 1) {                                                        // frag:637-641
-        float u = sobU, v = sobV;                                               // sobol(2b), sobol(2b+1) of this frame
-        cranley_patterson(uvx, uvy, F.width, F.height, u, v);
-        // SampleCosineHemisphere, frag:504-515; PI of frag:4 is 3.14159274f in fp32
-        const float r = __builtin_sqrtf(u);
-        const float theta = (v * 2.0f) * 3.14159274101257324f;
-        float sn, cs;
-        rtm::sincos_2pi_range(theta, sn, cs);
-        const float x = r * cs, y = r * sn;
-        const float z = __builtin_sqrtf(rtm::madd(-y, y, rtm::madd(-x, x, 1.0f)));
-        // toNormalHemisphere, frag:494-500.  For a triangle the frame depends on the triangle
-        // only and comes from its record (tangent_frame below, same arithmetic; negating the
-        // normal negates the tangent and leaves the bitangent, exactly).
-        if (!recFrame) tangent_frame(nrm, tangent, bitangent);
-        const vec3 L = rtm::mk(rtm::madd(z, nrm.x, rtm::madd(y, bitangent.x, x * tangent.x)),
-                               rtm::madd(z, nrm.y, rtm::madd(y, bitangent.y, x * tangent.y)),
-                               rtm::madd(z, nrm.z, rtm::madd(y, bitangent.z, x * tangent.z)));
-        p.d = rtm::normalize(L);
-        p.thr = rtm::scale(p.thr, 0.5f);
-    } else if (material == 2) {                                                 // frag:542-545
-        const float k = 2.0f * rtm::dot(nrm, p.d);
-        p.d = rtm::mk(rtm::madd(-k, nrm.x, p.d.x), rtm::madd(-k, nrm.y, p.d.y), rtm::madd(-k, nrm.z, p.d.z));
-    } else {                                                                    // frag:548-556
-        const vec3 n2 = rtm::scale(nrm, -rtm::dot(p.d, nrm));
-        vec3 t = rtm::add(p.d, n2);
-        t = rtm::mk(t.x / refraction, t.y / refraction, t.z / refraction);
-        p.d = rtm::normalize(rtm::sub(t, n2));
-    }
-    const int next = bounce + 1;
-    if (next >= F.maxBounces) return false;                                     // loop bound, frag:624
-    if (next > 1) {                                                             // frag:625-630
-        if (rand01(p.seed) > 0.8f) return false;
-    }
-    return true;
-}
-
-// frag:677-689: seed and camera ray of pixel (px,py)
-__device__ __forceinline__ void generate_path(const FrameD &F, float randOrigin, uint32_t px, uint32_t py,
-                                              Path &p, float &uvx, float &uvy) {
-    uvx = ((float)px + 0.5f) / (float)F.width;
-    uvy = ((float)py + 0.5f) / (float)F.height;
-    p.seed = (uint32_t)((randOrigin * 6.95857f) * (uvx * uvy));
-    p.o = rtm::mk(F.cam.camPos[0], F.cam.camPos[1], F.cam.camPos[2]);
-    const float sx = (uvx * 2.0f) * F.cam.halfW;
-    const float sy = (uvy * 2.0f) * F.cam.halfH;
-    const vec3 dir = rtm::mk(rtm::madd(sy, F.cam.up[0], rtm::madd(sx, F.cam.right[0], F.cam.leftbottom[0])),
-                             rtm::madd(sy, F.cam.up[1], rtm::madd(sx, F.cam.right[1], F.cam.leftbottom[1])),
-                             rtm::madd(sy, F.cam.up[2], rtm::madd(sx, F.cam.right[2], F.cam.leftbottom[2])));
-    p.d = rtm::normalize(dir);
-    p.thr = rtm::mk(1.0f, 1.0f, 1.0f);
-}
-
-// Pixel of lane `lane` in 8x8 tile `tile` (tiles numbered row-major over the image).
-__device__ __forceinline__ bool tile_pixel(int tile, int lane, int width, int height, uint32_t &px, uint32_t &py) {
-    const int tilesX = (width + 7) >> 3;
-    const int ty = tile / tilesX, tx = tile - ty * tilesX;
-    px = (uint32_t)(tx * 8 + (lane & 7));
-    py = (uint32_t)(ty * 8 + (lane >> 3));
-    return px < (uint32_t)width && py < (uint32_t)height;
-}
-
-// What an 8-bit unsigned-normalised colour attachment keeps of a value (RT_Screen.h:61).
-__device__ __forceinline__ float store_unorm8(float v) {
-    const float c = (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f;      // NaN -> 0
-    return floorf(c * 255.0f + 0.5f) / 255.0f;
-}
 
 __device__ __forceinline__ void flush_counters(WorkCounters *wc, uint32_t rays, uint32_t nNode, uint32_t nTri, uint32_t nHit) {
     // wave-level reduction, then one atomic per wave and counter

@@ -1,0 +1,214 @@
+// What the shader does around the BVH loop (device code, gfx950): random numbers, the camera
+// ray, material draw, spheres, scattering, Russian roulette (frag:36-104, 281-300, 457-689).
+// Included by rt_device.hip only; compile with -ffp-contract=off (rt_math.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_kernels.h"
+#include "rt_traverse.h"
+
+// Sobol direction numbers (uniform uint V[512], frag:81) live in constant memory: every lane
+// of a wave reads the same word, which the scalar unit serves.
+__constant__ uint32_t c_sobolV[RT_SOBOL_WORDS];
+
+namespace rtd {
+
+__device__ __forceinline__ float rand01(uint32_t &wseed) {     // frag:36-47
+    wseed = rtm::wang_step(wseed);
+    return (float)wseed * (1.0f / 4294967296.0f);
+}
+
+// frag:84-104 for one bounce: dims 2b and 2b+1 of frame `loopNum`.  loopNum and b are wave
+// uniform, so this runs on the scalar unit out of constant memory.
+__device__ __forceinline__ void sobol_pair(uint32_t loopNum, uint32_t b, float &u, float &v) {
+    uint32_t g = loopNum ^ (loopNum >> 1);
+    uint32_t r0 = 0u, r1 = 0u;
+    const uint32_t base = b * 64u;
+    for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
+        if (g & 1u) {
+            r0 ^= c_sobolV[base + j];
+            r1 ^= c_sobolV[base + 32u + j];
+        }
+    u = (float)r0 * (1.0f / 4294967296.0f);
+    v = (float)r1 * (1.0f / 4294967296.0f);
+}
+
+// frag:59-77
+__device__ __forceinline__ void cranley_patterson(float uvx, float uvy, int width, int height, float &px, float &py) {
+    const uint32_t X = (uint32_t)(rtm::madd(rtm::madd(uvx, 2.0f, -1.0f), 0.5f, 0.5f) * (float)width);
+    const uint32_t Y = (uint32_t)(rtm::madd(rtm::madd(uvy, 2.0f, -1.0f), 0.5f, 0.5f) * (float)height);
+    uint32_t pseed = (X * 1973u + Y * 9277u + (uint32_t)(114514 / 1919) * 26699u) | 1u;
+    pseed = rtm::wang_step(pseed);
+    const float u = (float)pseed / 4294967296.0f;
+    pseed = rtm::wang_step(pseed);
+    const float v = (float)pseed / 4294967296.0f;
+    float x = px + u;
+    if (x > 1.0f) x -= 1.0f;
+    if (x < 0.0f) x += 1.0f;
+    float y = py + v;
+    if (y > 1.0f) y -= 1.0f;
+    if (y < 0.0f) y += 1.0f;
+    px = x; py = y;
+}
+
+struct Path {
+    vec3 o, d, thr;
+    uint32_t seed;
+};
+
+// hitSphere, frag:281-293
+__device__ __forceinline__ float sphere_test(const RtSphere &s, const vec3 o, const vec3 d) {
+    const vec3 oc = rtm::sub(o, rtm::mk(s.center[0], s.center[1], s.center[2]));
+    const float a = rtm::dot(d, d);
+    const float b = 2.0f * rtm::dot(oc, d);
+    const float c = rtm::madd(-s.radius, s.radius, rtm::dot(oc, oc));
+    const float disc = rtm::madd(b, b, -((4.0f * a) * c));
+    if (disc > 0.0f) {
+        const float dis = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        return (dis > 0.0f) ? dis : -1.0f;
+    }
+    return -1.0f;
+}
+
+// frag:494-500: tangent and bitangent of a normal
+__host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tangent, vec3 &bitangent) {
+    const vec3 helper = (fabsf(nrm.x) > 0.999f) ? rtm::mk(0.0f, 0.0f, 1.0f) : rtm::mk(1.0f, 0.0f, 0.0f);
+    tangent = rtm::normalize(rtm::cross(nrm, helper));
+    bitangent = rtm::normalize(rtm::cross(nrm, tangent));
+}
+
+// Everything the shader does with a ray after the BVH loop: the rest of hitBVH
+// (frag:457-488), the sphere loop of hitWorld (frag:570-614), the material switch of
+// shading (frag:631-670), the 4*pi scaling (frag:672-673) and the Russian-roulette draw that
+// opens the next iteration (frag:625-630).  sobU/sobV are the frame's Sobol numbers for this
+// bounce (sobol_pair).  Returns true when the path goes on (p holds the next ray); otherwise
+// `sample` is the frame's radiance for the pixel.
+__device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
+                                          int bounce, float sobU, float sobV, float uvx, float uvy, vec3 &sample) {
+    sample = rtm::mk(0.0f, 0.0f, 0.0f);
+    bool hit = false;
+    float hitMin = HIT_MIN_INIT;
+    vec3 pos = rtm::mk(0, 0, 0), nrm = rtm::mk(0, 0, 0), albedo = rtm::mk(0, 0, 0);
+    int material = -1;
+    float refraction = 1.0f;
+    // tangent frame of the hit: taken from the triangle's record, computed for a sphere
+    bool recFrame = false;
+    vec3 tangent = rtm::mk(0, 0, 0), bitangent = rtm::mk(0, 0, 0);
+    if (tri != REF_NONE) {
+        const float4 *m = S.mats + (size_t)tri * 5;
+        const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4];
+        pos = rtm::along(p.o, tTri, p.d);                                       // frag:458
+        nrm = rtm::mk(m2.y, m2.z, m2.w);                                        // frag:296-300, precomputed
+        tangent = rtm::mk(m3.x, m3.y, m3.z);
+        bitangent = rtm::mk(m3.w, m4.x, m4.y);
+        recFrame = true;
+        if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
+        const float temp = rand01(p.seed);                                      // frag:462
+        const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
+        const float ksx = m1.z, ksy = m1.w;
+        if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }             // length(ka) > 0
+        else if (temp < ksx) { material = 1; albedo = kd; }
+        else if (temp < ksy) { material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f); }
+        else { material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f); refraction = 1.5f; }
+        if (tTri > 0.0f && tTri < hitMin) { hitMin = tTri; hit = true; }        // frag:562-565
+    }
+    for (int i = 0; i < F.sphereNum; i++) {                                     // frag:570-614
+        const RtSphere &s = F.sph[i];
+        const float dis = sphere_test(s, p.o, p.d);
+        if (dis > 0.0f && dis < hitMin) {
+            hitMin = dis;
+            hit = true;
+            const vec3 centre = rtm::mk(s.center[0], s.center[1], s.center[2]);
+            const vec3 n0 = rtm::sub(rtm::along(p.o, hitMin, p.d), centre);
+            const bool internal = rtm::dot(n0, p.d) > 0.0f;
+            const float temp = rand01(p.seed);
+            if (temp < s.specularRate) {
+                hitMin -= 0.00001f; material = 1; albedo = rtm::mk(s.albedo[0], s.albedo[1], s.albedo[2]);
+            } else if (temp < s.refractionRate) {
+                hitMin -= 0.00001f; material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f);
+            } else {
+                hitMin += 0.00001f; material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f);
+                refraction = internal ? 1.0f / 1.3f : 1.3f;
+            }
+            pos = rtm::along(p.o, hitMin, p.d);
+            nrm = rtm::sub(pos, centre);
+            recFrame = false;
+        }
+    }
+    if (!hit) return false;         // a miss can never reach a light afterwards (frag:655-672)
+    p.o = pos;
+    p.thr = rtm::mul(p.thr, albedo);                                            // frag:635
+    if (material == 0) {                                                        // frag:642-645
+        sample = rtm::scale(p.thr, 4.0f * 3.1415926f);                          // frag:673
+        return false;
+    }
+    if (material == 1) {                                                        // frag:637-641
+        float u = sobU, v = sobV;                                               // sobol(2b), sobol(2b+1) of this frame
+        cranley_patterson(uvx, uvy, F.width, F.height, u, v);
+        // SampleCosineHemisphere, frag:504-515; PI of frag:4 is 3.14159274f in fp32
+        const float r = __builtin_sqrtf(u);
+        const float theta = (v * 2.0f) * 3.14159274101257324f;
+        float sn, cs;
+        rtm::sincos_2pi_range(theta, sn, cs);
+        const float x = r * cs, y = r * sn;
+        const float z = __builtin_sqrtf(rtm::madd(-y, y, rtm::madd(-x, x, 1.0f)));
+        // toNormalHemisphere, frag:494-500.  For a triangle the frame depends on the triangle
+        // only and comes from its record (tangent_frame below, same arithmetic; negating the
+        // normal negates the tangent and leaves the bitangent, exactly).
+        if (!recFrame) tangent_frame(nrm, tangent, bitangent);
+        const vec3 L = rtm::mk(rtm::madd(z, nrm.x, rtm::madd(y, bitangent.x, x * tangent.x)),
+                               rtm::madd(z, nrm.y, rtm::madd(y, bitangent.y, x * tangent.y)),
+                               rtm::madd(z, nrm.z, rtm::madd(y, bitangent.z, x * tangent.z)));
+        p.d = rtm::normalize(L);
+        p.thr = rtm::scale(p.thr, 0.5f);
+    } else if (material == 2) {                                                 // frag:542-545
+        const float k = 2.0f * rtm::dot(nrm, p.d);
+        p.d = rtm::mk(rtm::madd(-k, nrm.x, p.d.x), rtm::madd(-k, nrm.y, p.d.y), rtm::madd(-k, nrm.z, p.d.z));
+    } else {                                                                    // frag:548-556
+        const vec3 n2 = rtm::scale(nrm, -rtm::dot(p.d, nrm));
+        vec3 t = rtm::add(p.d, n2);
+        t = rtm::mk(t.x / refraction, t.y / refraction, t.z / refraction);
+        p.d = rtm::normalize(rtm::sub(t, n2));
+    }
+    const int next = bounce + 1;
+    if (next >= F.maxBounces) return false;                                     // loop bound, frag:624
+    if (next > 1) {                                                             // frag:625-630
+        if (rand01(p.seed) > 0.8f) return false;
+    }
+    return true;
+}
+
+// frag:677-689: seed and camera ray of pixel (px,py)
+__device__ __forceinline__ void generate_path(const FrameD &F, float randOrigin, uint32_t px, uint32_t py,
+                                              Path &p, float &uvx, float &uvy) {
+    uvx = ((float)px + 0.5f) / (float)F.width;
+    uvy = ((float)py + 0.5f) / (float)F.height;
+    p.seed = (uint32_t)((randOrigin * 6.95857f) * (uvx * uvy));
+    p.o = rtm::mk(F.cam.camPos[0], F.cam.camPos[1], F.cam.camPos[2]);
+    const float sx = (uvx * 2.0f) * F.cam.halfW;
+    const float sy = (uvy * 2.0f) * F.cam.halfH;
+    const vec3 dir = rtm::mk(rtm::madd(sy, F.cam.up[0], rtm::madd(sx, F.cam.right[0], F.cam.leftbottom[0])),
+                             rtm::madd(sy, F.cam.up[1], rtm::madd(sx, F.cam.right[1], F.cam.leftbottom[1])),
+                             rtm::madd(sy, F.cam.up[2], rtm::madd(sx, F.cam.right[2], F.cam.leftbottom[2])));
+    p.d = rtm::normalize(dir);
+    p.thr = rtm::mk(1.0f, 1.0f, 1.0f);
+}
+
+// Pixel of lane `lane` in 8x8 tile `tile` (tiles numbered row-major over the image).
+__device__ __forceinline__ bool tile_pixel(int tile, int lane, int width, int height, uint32_t &px, uint32_t &py) {
+    const int tilesX = (width + 7) >> 3;
+    const int ty = tile / tilesX, tx = tile - ty * tilesX;
+    px = (uint32_t)(tx * 8 + (lane & 7));
+    py = (uint32_t)(ty * 8 + (lane >> 3));
+    return px < (uint32_t)width && py < (uint32_t)height;
+}
+
+// What an 8-bit unsigned-normalised colour attachment keeps of a value (RT_Screen.h:61).
+__device__ __forceinline__ float store_unorm8(float v) {
+    const float c = (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f;      // NaN -> 0
+    return floorf(c * 255.0f + 0.5f) / 255.0f;
+}
+
+}  // namespace rtd
