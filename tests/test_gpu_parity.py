@@ -415,6 +415,24 @@ def test_synthetic_mesh_parity_and_work_counters():
             assert s["node_tests"] == st["nodeTests"] and s["tri_tests"] == st["triTests"] and s["tri_hits"] == st["triHits"]
 
 
+@pytest.mark.parametrize("kind,level,copies,bounces", [(1, 6, 1, 4), (0, 3, 8, 8)])
+def test_benchmark_scene_families_at_low_subdivision(kind, level, copies, bounces):
+    """The other two benchmark scenes in small: the column hall (diffuse / mirror / glass columns,
+    two spheres, room scaled x3) and eight copies of the displaced mesh with 8 bounces."""
+    W, H = 128, 72
+    sc = rt.Scene()
+    sc.push_synthetic(kind, level, copies, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 3)
+    want, st = _oracle_for(tris, nodes, W, H, sc.spheres(), max_bounces=bounces).render(cam, 1, ro, want_stats=True)
+    res = _render_all_pipelines(tris, nodes, cam, ro, W, H, spheres=sc.spheres(), bounces=bounces)
+    for name, (img, rays) in res.items():
+        assert _same_image(img, want), (kind, name)
+        assert rays == st["rays"], (kind, name)
+    assert np.nan_to_num(want).max() > 0
+
+
 def test_full_size_properties_1080p():
     """At the benchmark resolution the oracle is too slow for every pixel; check properties:
     both pipelines and both traversal modes give the same image; rendering frames in two calls
