@@ -253,6 +253,11 @@ int rt_synchronize(RtContext *ctx);
 int rt_read_mean(RtContext *ctx, float *rgb);
 /* Plain fp32 sum of all samples since rt_reset (what a multi-GPU reduce adds up). */
 int rt_read_sum(RtContext *ctx, float *rgb);
+/* Resume an interrupted render: loads a running mean and a sum read earlier with rt_read_mean /
+ * rt_read_sum (W*H*3 floats each, NULL keeps the current content) and sets the frame count.
+ * The caller continues with first_loopnum = frames + 1.  No counterpart in the reference, whose
+ * accumulation lives only in its two FBO textures and is lost on exit. */
+int rt_restore(RtContext *ctx, const float *mean_rgb, const float *sum_rgb, uint64_t frames);
 /* Device address of the W*H*3 fp32 sum buffer (for a caller-side collective). */
 int rt_sum_device_ptr(RtContext *ctx, void **dev_ptr);
 /* Accumulate sums into caller-owned device memory (W*H*3 floats) instead; NULL restores the

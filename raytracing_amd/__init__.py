@@ -104,6 +104,7 @@ _PROTOS = {
     "rt_synchronize": (_int, [_vp]),
     "rt_read_mean": (_int, [_vp, _vp]),
     "rt_read_sum": (_int, [_vp, _vp]),
+    "rt_restore": (_int, [_vp, _vp, _vp, C.c_uint64]),
     "rt_sum_device_ptr": (_int, [_vp, C.POINTER(_vp)]),
     "rt_bind_sum_buffer": (_int, [_vp, _vp]),
     "rt_get_stats": (_int, [_vp, C.POINTER(RtStats)]),
@@ -338,6 +339,15 @@ class Renderer:
         out = np.zeros((self.height, self.width, 3), dtype=np.float32)
         _check(lib.rt_read_sum(self._h, _ptr(out)), self._h)
         return out
+
+    def restore(self, mean, sum_, frames):
+        """Resume: load a running mean and a sum saved earlier; continue with render(frames + 1, ...)."""
+        m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
+        s = None if sum_ is None else np.ascontiguousarray(sum_, dtype=np.float32)
+        for a in (m, s):
+            if a is not None and a.shape != (self.height, self.width, 3):
+                raise ValueError("restore: images must be (height, width, 3)")
+        _check(lib.rt_restore(self._h, None if m is None else _ptr(m), None if s is None else _ptr(s), frames), self._h)
 
     def bind_sum_buffer(self, dev_ptr):
         _check(lib.rt_bind_sum_buffer(self._h, C.c_void_p(dev_ptr)), self._h)

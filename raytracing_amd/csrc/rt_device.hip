@@ -1163,6 +1163,18 @@ int rt_read_sum(RtContext *ctx, float *rgb) {
     return RT_OK;
 }
 
+int rt_restore(RtContext *ctx, const float *mean_rgb, const float *sum_rgb, uint64_t frames) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_restore: null context");
+    if (frames >= ((uint64_t)1 << 30)) return fail(ctx, RT_E_INVALID, "rt_restore: frame count out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t img = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    if (mean_rgb) HIP_TRY(ctx, hipMemcpyAsync(ctx->dMean, mean_rgb, img, hipMemcpyHostToDevice, ctx->stream));
+    if (sum_rgb) HIP_TRY(ctx, hipMemcpyAsync(ctx->dSum, sum_rgb, img, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->frames = frames;
+    return RT_OK;
+}
+
 int rt_sum_device_ptr(RtContext *ctx, void **dev_ptr) {
     if (!ctx || !dev_ptr) return fail(ctx, RT_E_INVALID, "rt_sum_device_ptr: null pointer");
     *dev_ptr = ctx->dSum;

@@ -251,6 +251,40 @@ def test_small_and_awkward_scenes(case):
         assert np.nan_to_num(want).max() > 0 or case == "one_triangle"
 
 
+def test_resume_from_saved_accumulation():
+    """rt_restore: 3 frames, save mean + sum, a new context restores them and renders 3 more:
+    the same images as 6 frames in one go."""
+    W, H = 80, 48
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(12, 6)
+
+    def fresh():
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        return r
+    r = fresh()
+    r.render(1, ro)
+    want_mean, want_sum = r.read_mean(), r.read_sum()
+    r.close()
+    r = fresh()
+    r.render(1, ro[:3])
+    mean3, sum3 = r.read_mean(), r.read_sum()
+    assert r.stats()["frames"] == 3
+    r.close()
+    r = fresh()
+    r.restore(mean3, sum3, 3)
+    assert r.stats()["frames"] == 3
+    r.render(4, ro[3:])
+    assert np.array_equal(r.read_mean(), want_mean) and np.array_equal(r.read_sum(), want_sum)
+    assert r.stats()["frames"] == 6
+    with pytest.raises(rt.RtError):
+        r.restore(None, None, 1 << 31)
+
+
 def test_golden_vectors(golden_dir):
     """Committed expected values (made by the oracle from the reference's scene files)."""
     import os
