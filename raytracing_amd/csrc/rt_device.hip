@@ -244,10 +244,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
             if (__ballot(exact) != 0ull) {
                 // Rare (a few rays per million): trace those rays again in the reference's order,
                 // right here.  The wave's other lanes wait; the other waves of the CU do not.
-                // The lane's deferred-node column is empty at this point and is reused.
+                // The lane's global overflow column is empty at this point and serves as the stack.
                 if (exact) {
                     float t; uint32_t tri;
-                    closest_triangle<true, COUNT>(S, tv.o, tv.d, stack, BLOCK, t, tri, cNode, cTri);
+                    closest_triangle<true, COUNT>(S, tv.o, tv.d, ovf, (int)S.aovfStride, t, tri, cNode, cTri);
                     tv.hitMin = t; tv.best = tri;
                     atomicAdd(&wc->retraced, 1ull);
                 }
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                 if (__ballot(exact) != 0ull) {
                     if (exact) {
                         float t; uint32_t tri;
-                        closest_triangle<true, COUNT>(S, tv.o, tv.d, stack, BLOCK, t, tri, cNode, cTri);
+                        closest_triangle<true, COUNT>(S, tv.o, tv.d, ovf, (int)S.aovfStride, t, tri, cNode, cTri);
                         tv.hitMin = t; tv.best = tri;
                         atomicAdd(&wc->retraced, 1ull);
                     }
@@ -613,7 +613,7 @@ struct RtContext {
     // scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
     float4 *dANodes = nullptr; uint32_t *dAOvf = nullptr;      // search index: nodes, overflow of the deferred-node stack
-    int accelLdsEntries = 20;
+    int accelLdsEntries = 16;
     int64_t nTris = 0, nInterior = 0;
     SceneD scene{};
     bool haveScene = false;
@@ -636,7 +636,7 @@ struct RtContext {
     // persistent-path pipeline: one sample image per frame of a batch, and the item counter
     float *dCurBatch = nullptr; int curBatchFrames = 0;
     uint32_t *dWorkHead = nullptr;
-    int pathsOcc = 6;           // waves per SIMD the path kernel is compiled for (5, 6 or 7)
+    int pathsOcc = 0;           // waves per SIMD the path kernel is compiled for (5, 6 or 7); 0 = by scene size
     int pathsLeafBatch = 8;     // lanes waiting for a triangle pass that trigger one in the path kernel
     WorkCounters *dCounters = nullptr;
     uint64_t frames = 0;
@@ -787,8 +787,8 @@ int ensure_sobol(RtContext *ctx) {
 }
 
 size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
-// the fast kernel's LDS column also serves the in-place exact re-trace
-size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)std::max(ctx->scene.aldsEntries + FAST_QUEUE_ENTRIES, ctx->scene.stackEntries) * BLOCK * sizeof(uint32_t); }
+// triangle queue + deferred nodes of the index search (the in-place exact re-trace uses the global overflow column)
+size_t fast_stack_bytes(const RtContext *ctx) { return (size_t)(ctx->scene.aldsEntries + FAST_QUEUE_ENTRIES) * BLOCK * sizeof(uint32_t); }
 
 }  // namespace
 
@@ -942,7 +942,8 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         const int need = std::max(accel.wideStack, 1);
         S.aldsEntries = std::min(need, ctx->accelLdsEntries);
         S.aovfStride = (uint32_t)ctx->numCU * 8u * BLOCK;
-        const size_t ovfEntries = (size_t)std::max(need - S.aldsEntries, 1) * S.aovfStride;
+        // overflow column per thread: the deeper deferred nodes, or the whole stack of an exact re-trace
+        const size_t ovfEntries = (size_t)std::max(std::max(need - S.aldsEntries, S.stackEntries), 1) * S.aovfStride;
         HIP_TRY(ctx, hipMalloc(&ctx->dAOvf, ovfEntries * sizeof(uint32_t)));
         S.aovf = ctx->dAOvf;
     }
@@ -1070,7 +1071,10 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         if (!ctx->dWorkHead) HIP_TRY(ctx, hipMalloc(&ctx->dWorkHead, 128));
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
-        const int blocks = ctx->numCU * (fast ? std::min(std::max(ctx->pathsOcc, 5), 7) : 5);
+        // Occupancy against spills: large scenes have more memory latency to hide (7 waves per
+        // SIMD, 16 spilled values), small ones spend their time in the finish block (6 waves, 7 spilled).
+        const int occ = ctx->pathsOcc ? std::min(std::max(ctx->pathsOcc, 5), 7) : (ctx->nTris >= 65536 ? 7 : 6);
+        const int blocks = ctx->numCU * (fast ? occ : 5);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
         SceneD Sp = S;
         Sp.leafBatch = ctx->pathsLeafBatch;
@@ -1088,8 +1092,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
 #define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, st, Sp, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
             if (fast) {
                 if (cnt) LAUNCH_PATHS(true, true, true, 5);
-                else if (ctx->pathsOcc == 5) LAUNCH_PATHS(true, true, false, 5);
-                else if (ctx->pathsOcc == 7) LAUNCH_PATHS(true, true, false, 7);
+                else if (occ == 5) LAUNCH_PATHS(true, true, false, 5);
+                else if (occ == 7) LAUNCH_PATHS(true, true, false, 7);
                 else LAUNCH_PATHS(true, true, false, 6);
             }
             else if (cull) { if (cnt) LAUNCH_PATHS(false, true, true, 5); else LAUNCH_PATHS(false, true, false, 5); }
