@@ -1,5 +1,12 @@
 #!/usr/bin/env python3
-"""Experiment: prints the wave-level block counts of a library built with -DRT_EXP_PROFILE."""
+"""Experiment: prints the wave-level block counts of the path kernel (iterations, node / triangle /
+finish block executions and the lanes active in each).  Needs a library built with the counters:
+
+  hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -DRT_EXP_PROFILE \
+        -o /tmp/librt_profile.so raytracing_amd/csrc/rt_{device.hip,bvh.cpp,host.cpp,scene.cpp,accel.cpp} -lpthread
+  RT_AMD_LIBRARY=/tmp/librt_profile.so python3 tools/exp_profile.py
+
+(the counters reuse the work-counter fields, so that build reports no box/triangle statistics)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracing_amd as rt
