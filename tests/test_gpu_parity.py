@@ -285,6 +285,31 @@ def test_resume_from_saved_accumulation():
         r.restore(None, None, 1 << 31)
 
 
+def test_1024_spp_running_mean_rmse():
+    """The accumulation bar: after 1024 frames the running mean equals the oracle's (RMSE 0, far
+    inside the 1e-3 bound), the sum / N agrees with it to rounding, and the image has converged
+    towards the 256-frame one."""
+    W, H, N = 96, 54, 1024
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, N)
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    r.set_spheres(sc.spheres())
+    r.set_camera(cam)
+    r.render(1, ro[:256])
+    at256 = r.read_mean()
+    r.render(257, ro[256:])
+    got = r.read_mean()
+    want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro)
+    rmse = float(np.sqrt(np.mean((got.astype(np.float64) - want.astype(np.float64)) ** 2)))
+    assert rmse <= 1e-3 and np.array_equal(got, want), rmse
+    assert float(np.sqrt(np.mean((r.read_sum() / np.float32(N) - want) ** 2))) < 1e-4
+    assert r.stats()["frames"] == N
+    assert float(np.abs(got - at256).mean()) < 0.05
+
+
 def test_golden_vectors(golden_dir):
     """Committed expected values (made by the oracle from the reference's scene files)."""
     import os
