@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon1m", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=64,
+                    help="frames per step; the path kernel renders up to 64 frames per launch")
     ap.add_argument("--pipeline", default="persistent", choices=["wavefront", "megakernel", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")

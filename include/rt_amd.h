@@ -110,7 +110,7 @@ typedef struct RtOptions {
 #define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
 #define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */
 #define RT_PIPELINE_PERSISTENT 2  /* persistent waves; each lane runs whole paths and takes the next (frame, pixel)
-                                     when one ends; up to 16 frames of an rt_render_frames call share a launch */
+                                     when one ends; up to 64 frames of an rt_render_frames call share a launch */
 
 typedef struct RtContext RtContext;
 typedef struct RtScene RtScene;     /* host-side scene assembly (Scene.h) */

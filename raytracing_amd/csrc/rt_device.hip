@@ -359,10 +359,25 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
 
 struct BatchD {                     // the frames one launch of k_paths renders
     int32_t firstLoopNum;
-    int32_t nframes;                // 1..PATHS_MAX_FRAMES
-    float randOrigin[16];
+    int32_t nframes;                // 1..PATHS_MAX_FRAMES, and < 2^(32 - bitsX - bitsY)
+    int32_t bitsX, bitsY;           // a lane's pixel word: px | py << bitsX | frame slot << (bitsX + bitsY)
+    float randOrigin[64];
 };
-constexpr int PATHS_MAX_FRAMES = 16;        // frame slot is kept in 4 bits of the lane's pixel word
+constexpr int PATHS_MAX_FRAMES = 64;
+
+// Sobol numbers of every (frame slot, bounce) of a batch: they do not depend on the pixel
+// (frag:99-104).  table[(slot * maxBounces + bounce) * 2 + {0,1}].
+__global__ void k_sobol_table(const BatchD B, const int maxBounces, float *__restrict__ table) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B.nframes * maxBounces * 2) return;
+    const int f = t / (maxBounces * 2), r = t - f * (maxBounces * 2);
+    const uint32_t loopNum = (uint32_t)(B.firstLoopNum + f);
+    uint32_t g = loopNum ^ (loopNum >> 1), acc = 0u;
+    const uint32_t base = (uint32_t)(r >> 1) * 64u + (uint32_t)(r & 1) * 32u;
+    for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
+        if (g & 1u) acc ^= c_sobolV[base + j];
+    table[t] = (float)acc * (1.0f / 4294967296.0f);
+}
 
 // Whole paths in one launch: persistent waves, each lane owns one path at a time and runs it
 // from the camera ray to its end (generate, extend, shade, extend, ... as frag:677-689 +
@@ -380,23 +395,10 @@ constexpr int PATHS_MAX_FRAMES = 16;        // frame slot is kept in 4 bits of t
 // otherwise the reference's tree in the reference's order (Trav<CULL>).
 template <bool FAST, bool CULL, bool COUNT, int OCC>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths(const SceneD S, const FrameD F, const BatchD B,
-                                                 uint32_t *__restrict__ workHead, float *__restrict__ cur,
+                                                 const float *__restrict__ sob, uint32_t *__restrict__ workHead, float *__restrict__ cur,
                                                  WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_dyn[];
-    // Sobol numbers of every (frame slot, bounce): they do not depend on the pixel (frag:99-104)
-    float *sob = reinterpret_cast<float *>(lds_dyn);
-    const int sobWords = B.nframes * F.maxBounces * 2;
-    for (int t = threadIdx.x; t < sobWords; t += BLOCK) {
-        const int f = t / (F.maxBounces * 2), r = t - f * (F.maxBounces * 2);
-        const uint32_t loopNum = (uint32_t)(B.firstLoopNum + f);
-        uint32_t g = loopNum ^ (loopNum >> 1), acc = 0u;
-        const uint32_t base = (uint32_t)(r >> 1) * 64u + (uint32_t)(r & 1) * 32u;
-        for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
-            if (g & 1u) acc ^= c_sobolV[base + j];
-        sob[t] = (float)acc * (1.0f / 4294967296.0f);
-    }
-    __syncthreads();
-    uint32_t *stack = lds_dyn + ((sobWords + 63) & ~63) + threadIdx.x;
+    uint32_t *stack = lds_dyn + threadIdx.x;
     uint32_t *ovf = FAST ? S.aovf + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -411,7 +413,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
     tv.cur = REF_NONE;
     if constexpr (FAST) tv.npend = 0;
     bool have = false;
-    uint32_t pix = 0;                                   // px | py << 14 | frame slot << 28
+    uint32_t pix = 0;                                   // px | py << bitsX | frame slot << (bitsX + bitsY)
+    const uint32_t maskX = (1u << B.bitsX) - 1u, maskY = (1u << B.bitsY) - 1u;
+    const int shiftSlot = B.bitsX + B.bitsY;
     int bounce = 0;
     vec3 thr = rtm::mk(0.0f, 0.0f, 0.0f);
     uint32_t seed = 0;
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
             if (fin) {
                 cRays++;
                 if (COUNT && tv.best != REF_NONE) cHit++;
-                const uint32_t px = pix & 0x3FFFu, py = (pix >> 14) & 0x3FFFu, slot = pix >> 28;
+                const uint32_t px = pix & maskX, py = (pix >> B.bitsX) & maskY, slot = pix >> shiftSlot;
                 const float uvx = ((float)px + 0.5f) / (float)F.width;
                 const float uvy = ((float)py + 0.5f) / (float)F.height;
                 const int si = ((int)slot * F.maxBounces + bounce) * 2;
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                     Path p; float uvx, uvy;
                     generate_path(F, B.randOrigin[slot], px, py, p, uvx, uvy);
                     thr = p.thr; seed = p.seed; bounce = 0;
-                    pix = px | (py << 14) | (slot << 28);
+                    pix = px | (py << B.bitsX) | (slot << shiftSlot);
                     nextO = p.o; nextD = p.d; startRay = true;
                     have = true;
                 }
@@ -635,6 +639,7 @@ struct RtContext {
     float *dRandOrigin = nullptr; int randCap = 0;
     // persistent-path pipeline: one sample image per frame of a batch, and the item counter
     float *dCurBatch = nullptr; int curBatchFrames = 0;
+    float *dSobTable = nullptr;     // k_sobol_table output for one batch
     uint32_t *dWorkHead = nullptr;
     int pathsOcc = 0;           // waves per SIMD the path kernel is compiled for (5, 6 or 7); 0 = by scene size
     int pathsLeafBatch = 8;     // lanes waiting for a triangle pass that trigger one in the path kernel
@@ -879,7 +884,7 @@ void rt_destroy(RtContext *ctx) {
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
     hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
-    hipFree(ctx->dCurBatch); hipFree(ctx->dWorkHead);
+    hipFree(ctx->dCurBatch); hipFree(ctx->dWorkHead); hipFree(ctx->dSobTable);
     delete ctx;
 }
 
@@ -1059,16 +1064,21 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
 
     if (ctx->opt.pipeline == RT_PIPELINE_PERSISTENT) {
         const size_t nfloats = (size_t)ctx->width * ctx->height * 3;
+        int bitsX = 1, bitsY = 1;       // bits of the largest pixel coordinates
+        while ((1 << bitsX) < ctx->width) bitsX++;
+        while ((1 << bitsY) < ctx->height) bitsY++;
         if (!ctx->dCurBatch) {
-            // frames per launch: up to 16, within 2 GiB of sample images and 2^31 items
+            // frames per launch: up to 64, within 2 GiB of sample images, 2^31 items and the slot bits of the pixel word
             const size_t perFrame = nfloats * sizeof(float);
             int g = (int)std::min<size_t>(PATHS_MAX_FRAMES, std::max<size_t>(1, ((size_t)2 << 30) / perFrame));
+            g = std::min(g, (int)std::min<uint32_t>(64u, 1u << (32 - bitsX - bitsY)));
             g = (int)std::min<size_t>((size_t)g, std::max<size_t>(1, ((size_t)1 << 31) / ((size_t)tiles * 64 + 1)));
             if (const char *env = getenv("RT_AMD_BATCH_FRAMES")) { const int v = atoi(env); if (v >= 1 && v < g) g = v; }
             HIP_TRY(ctx, hipMalloc(&ctx->dCurBatch, (size_t)g * perFrame));
             ctx->curBatchFrames = g;
         }
         if (!ctx->dWorkHead) HIP_TRY(ctx, hipMalloc(&ctx->dWorkHead, 128));
+        if (!ctx->dSobTable) HIP_TRY(ctx, hipMalloc(&ctx->dSobTable, (size_t)PATHS_MAX_FRAMES * RT_MAX_BOUNCES * 2 * sizeof(float)));
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
         // Occupancy against spills: large scenes have more memory latency to hide (7 waves per
@@ -1082,14 +1092,16 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             BatchD B;
             B.firstLoopNum = first_loopnum + off;
             B.nframes = std::min(ctx->curBatchFrames, count - off);
+            B.bitsX = bitsX; B.bitsY = bitsY;
             for (int f = 0; f < PATHS_MAX_FRAMES; f++) B.randOrigin[f] = f < B.nframes ? rand_origin[off + f] : 0.0f;
-            const size_t sobBytes = (size_t)((B.nframes * F.maxBounces * 2 + 63) & ~63) * sizeof(uint32_t);
-            const size_t ldsP = sobBytes + (fast ? fast_stack_bytes(ctx) : lds);
+            const size_t ldsP = fast ? fast_stack_bytes(ctx) : lds;
+            const int sobWords = B.nframes * F.maxBounces * 2;
+            hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, st, B, F.maxBounces, ctx->dSobTable);
             HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkHead, 0, sizeof(uint32_t), st));
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, st));
-#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, st, Sp, F, B, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
+#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, st, Sp, F, B, ctx->dSobTable, ctx->dWorkHead, ctx->dCurBatch, ctx->dCounters)
             if (fast) {
                 if (cnt) LAUNCH_PATHS(true, true, true, 5);
                 else if (occ == 5) LAUNCH_PATHS(true, true, false, 5);

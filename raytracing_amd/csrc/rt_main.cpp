@@ -107,7 +107,7 @@ int main(int argc, char **argv) {
     uint32_t state = seed;
     for (int f = 0; f < spp; f++) ro[(size_t)f] = rt_rand_origin(&state);                                         // main.cpp:149
     t0 = std::chrono::steady_clock::now();
-    const int batch = 16;
+    const int batch = 64;       // the path kernel renders up to 64 frames per launch
     for (int first = 1; first <= spp; first += batch) {
         const int cnt = (spp - first + 1 < batch) ? spp - first + 1 : batch;
         if (rt_render_frames(ctx, first, cnt, ro.data() + (first - 1)) != RT_OK) return die("rt_render_frames", ctx);

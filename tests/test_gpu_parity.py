@@ -128,13 +128,13 @@ def test_demo_one_spp_and_running_mean(pipeline, cull, accel):
 
 
 def test_persistent_pipeline_frame_batches():
-    """37 frames in one call: the persistent pipeline renders them 16 per launch (three launches,
+    """150 frames in one call: the persistent pipeline renders them 64 per launch (three launches,
     the last one partial) and must reproduce the frame-by-frame running mean and sum."""
     W, H = 72, 40
     sc = scenes.demo()
     tris, nodes = rt.bvh_build(sc.triangles())
     cam = rt.camera_default(W, H)
-    ro = rt.rand_origins(99, 37)
+    ro = rt.rand_origins(99, 150)
     want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro)
     res = {}
     for pipeline in (rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT):

@@ -35,18 +35,33 @@ __global__ void k4(float *out, int n, int scattered, int iters) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
 }
+__global__ void k8(float *out, int n, int scattered, int iters) {
+    const int lane = threadIdx.x & 63;
+    float a[8]; const float b = 1.0001f, c = 0.5f;
+    for (int j = 0; j < 8; j++) a[j] = (float)threadIdx.x * 1e-3f + (float)j;
+    if (lane_on(lane, n, scattered)) {
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = __builtin_fmaf(a[j], b, c);
+        }
+    }
+    float r = 0.0f;
+    for (int j = 0; j < 8; j++) r += a[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
 int main(int argc, char **argv) {
     const int blocksPerCU = argc > 1 ? atoi(argv[1]) : 8;
     float *d; if (hipMalloc(&d, 256 * 2048 * 8 * sizeof(float)) != hipSuccess) return 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int ns[] = {64, 63, 48, 33, 32, 31, 24, 17, 16, 15, 8, 1};
     printf("blocks per CU %d (waves per SIMD %d)\n", blocksPerCU, blocksPerCU);
-    for (int kern = 0; kern < 2; kern++)
+    for (int kern = 0; kern < 3; kern++)
         for (int scattered = 0; scattered < 2; scattered++)
             for (int n : ns) {
                 auto launch = [&](int iters) {
                     if (kern == 0) k1<<<256 * blocksPerCU, 256>>>(d, n, scattered, iters);
-                    else k4<<<256 * blocksPerCU, 256>>>(d, n, scattered, iters);
+                    else if (kern == 1) k4<<<256 * blocksPerCU, 256>>>(d, n, scattered, iters);
+                    else k8<<<256 * blocksPerCU, 256>>>(d, n, scattered, iters);
                 };
                 launch(100);
                 hipDeviceSynchronize();
@@ -54,7 +69,7 @@ int main(int argc, char **argv) {
                 launch(20000);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
-                printf("%s %s n=%2d  %.3f ms\n", kern ? "4 chains" : "1 chain ", scattered ? "scattered " : "contiguous", n, ms);
+                printf("%s %s n=%2d  %.3f ms\n", kern == 2 ? "8 chains" : (kern ? "4 chains" : "1 chain "), scattered ? "scattered " : "contiguous", n, ms);
             }
     return 0;
 }

@@ -18,8 +18,8 @@ def main():
     ap.add_argument("--demo", action="store_true")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--pipeline", type=int, default=2)
     ap.add_argument("--no-cull", action="store_true")
