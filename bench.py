@@ -7,6 +7,8 @@ A step is one pass of the hot path over one batch: `--spp-per-step` frames (samp
 of the workload at its full resolution.  For N > 1 the driver launches one process per GPU with
 torch.distributed.run; every rank renders its own block of frame indices (weak scaling), and
 the per-rank fp32 sums are reduced to rank 0 by one RCCL reduce inside the timed region.
+With `--total-spp S` the job is fixed instead (strong scaling): S frames in all, S / (N * K) per
+rank and step.
 
 Prints ONE JSON line on rank 0.  `value` is Mrays/s over all ranks: rays actually traced
 (camera ray + one per scatter; rays that already missed are not re-traced) divided by the
@@ -70,6 +72,31 @@ def cpu_baseline(rt, tris, nodes, spheres, cam, W, H, bounces, ro, budget_s=15.0
                       "oracle/rt_oracle.c with OpenMP over rows; no hitMin culling, re-traces excluded from the count"}
 
 
+def call_granularity(r, ro, bounces, pipeline, args, frames=64):
+    """The drop-in call pattern: the reference's main loop (main.cpp:124-172) renders ONE frame per
+    iteration, i.e. rt_render_frames(ctx, LoopNum, 1, &randOrigin).  Times `frames` frames issued
+    as calls of 1 and of 8 frames (no host synchronisation between calls) next to the batched
+    figure of the main measurement."""
+    out = []
+    frames = min(frames, len(ro) // 8 * 8)
+    if frames < 8:
+        return out
+    r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False, accel=not args.no_accel)
+    for per_call in (1, 8):
+        for timed in (False, True):                         # one untimed pass first
+            r.reset()
+            r.synchronize()
+            t0 = time.perf_counter()
+            for first in range(1, frames + 1, per_call):
+                r.render(first, ro[first - 1:first - 1 + per_call])
+            r.synchronize()
+            dt = time.perf_counter() - t0
+        rays = r.stats()["rays"]
+        out.append({"frames_per_call": per_call, "calls": frames // per_call, "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+                    "ms_per_call": round(dt / (frames // per_call) * 1e3, 4)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +110,11 @@ def main():
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
     ap.add_argument("--resolution", default=None, help="WxH override for sensitivity runs (the named workload's resolution is the default)")
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="strong scaling: this many frames in the whole job, split evenly over ranks and steps "
+                         "(overrides --spp-per-step; must be divisible by gpus * steps)")
+    ap.add_argument("--no-call-granularity", action="store_true",
+                    help="skip the extra measurement of 1 and 8 frames per rt_render_frames call")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a one-GPU box: every rank uses GPU 0 and the reduce goes through gloo")
     args = ap.parse_args()
@@ -126,8 +158,13 @@ def main():
     r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False, accel=not args.no_accel)
     sum_t = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     r.bind_sum_buffer(sum_t.data_ptr())
+    info = r.scene_info()
 
     F, K, Wm = args.spp_per_step, args.steps, args.warmup
+    if args.total_spp:
+        if args.total_spp % (world * K):
+            raise SystemExit("--total-spp must be divisible by gpus * steps")
+        F = args.total_spp // (world * K)
     total_frames = (K + Wm) * world * F
     ro = partition.rand_origin_stream(SEED, total_frames)
 
@@ -198,46 +235,64 @@ def main():
         # fp32 vector work: 21 ops per box test, 95 per triangle test, 150 per shaded ray
         flops_per_ray = (21.0 * w["node_tests"] + 95.0 * w["tri_tests"]) / rays_w + 150.0
         valu_tflops = flops_per_ray * rays_local / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        # traffic beyond L2 of the dominant kernel from the committed PMC passes of the same workload
+        # Counters of the dominant kernel from the committed PMC passes of the same workload
+        # (profiles/r02_pmc_<workload>.json, made by tools/pmc_to_json.py): traffic beyond L2,
+        # vector issue rate and lane utilisation.  Only used when they describe this configuration.
         traffic = None
-        valu_issue = None
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if (pmc["workload"] == args.workload and not args.no_accel and args.pipeline == pmc["pipeline"]
-                    and F == pmc["frames_per_dispatch"] and not args.resolution):
+            cand = json.load(open(pmc_path))
+            if (cand["workload"] == args.workload and not args.no_accel and args.pipeline == cand["pipeline"]
+                    and min(F, info["frames_per_launch"]) == cand["frames_per_dispatch"] and not args.resolution):
+                pmc = cand
                 traffic = round((pmc["fetch_size_kb_per_dispatch"] * pmc["fetch_correction"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
-                valu_issue = pmc.get("valu_issue_slots_busy")
         except (OSError, KeyError, ValueError):
-            traffic = None
+            pmc = None
         dominant = {rt.PIPELINE_WAVEFRONT: "k_extend" if args.no_accel else "k_extend_fast",
                     rt.PIPELINE_MEGAKERNEL: "k_megakernel", rt.PIPELINE_PERSISTENT: "k_paths"}[pipeline]
         result = {
             "metric": "Mrays/sec (paths x bounces) at 1080p" if H == 1080 else "Mrays/sec (paths x bounces)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if args.total_spp else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc} (BASELINE.json configs[{cfg_idx}])",
                        "triangles": int(tris.shape[0]), "bvh_nodes": int(nodes.shape[0]),
-                       "resolution": f"{W}x{H}", "spp_per_step": F, "max_bounces": bounces,
+                       "resolution": f"{W}x{H}", "spp_per_step": F, "frames_per_call": F,
+                       "frames_per_launch": min(F, info["frames_per_launch"]), "total_spp": K * world * F, "max_bounces": bounces,
                        "pipeline": args.pipeline, "cull": not args.no_cull, "search_index": not args.no_accel,
                        "parallelism": f"spp-partition x{world}, one RCCL sum-reduce" if world > 1 else "single GPU",
                        "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
                        "image_mean": float(mean_img.mean())},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch beyond L2 (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json; includes Infinity Cache hits)",
-                         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_local / max(launches, 1)),
-                         "note": "scene data is cache resident: algorithmic bytes are mostly served by L1/L2/Infinity Cache, "
-                                 "the kernel is bound by vector-ALU issue (see valu_* and DESIGN.md), `achieved` is not HBM traffic",
-                         "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_box": node_b,
-                         "bytes_per_ray_at_32B_per_box": round(binary_bpr, 1),
-                         "valu_tflops": round(valu_tflops, 2), "valu_frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
-                         "valu_issue_slots_busy": valu_issue,     # from the PMC run (SQ_INSTS_VALU), see profiles/r01_pmc_traffic.json
+            # The scene (index + triangles) is served by L1 / L2 / Infinity Cache, so the roof that
+            # binds is the fp32 vector unit, not HBM: `achieved` is the algorithmic fp32 work (21 flop
+            # per box tested, 95 per triangle tested, 150 per ray shaded) over the kernel's time.
+            "roofline": {"bound": "valu", "kernel": dominant, "achieved": round(valu_tflops, 3), "peak": VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch beyond L2 (PMC FETCH_SIZE x2 + WRITE_SIZE; includes Infinity Cache hits)",
+                         "traffic_source": os.path.relpath(pmc_path, ROOT) if pmc else None,
+                         "flops_per_ray": round(flops_per_ray, 1),
+                         "kernel_ms_per_launch": round(kernel_ms / max(launches, 1), 4), "launches": launches,
+                         "kernel_share_of_wall": round(kernel_ms * 1e-3 / elapsed, 3),
+                         "waves_per_simd": info["paths_waves_per_simd"] if pipeline == rt.PIPELINE_PERSISTENT else None,
                          "nodes_per_ray": round(w["node_tests"] / rays_w, 2),
                          "tris_per_ray": round(w["tri_tests"] / rays_w, 2),
-                         "kernel_ms_per_launch": round(kernel_ms / max(launches, 1), 4), "launches": launches,
-                         "kernel_share_of_wall": round(kernel_ms * 1e-3 / elapsed, 3)},
+                         # memory side, for context: algorithmic bytes (what the caches serve) and HBM-side traffic
+                         "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_box": node_b,
+                         "bytes_per_ray_at_32B_per_box": round(binary_bpr, 1),
+                         "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_local / max(launches, 1)),
+                         "cache_served_tbps": round(achieved / 1e3, 3),
+                         "hbm_frac": (round(traffic / (kernel_ms / max(launches, 1) * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+                                      if traffic and kernel_ms > 0 else None),
+                         "hbm_note": "hbm_frac = PMC traffic beyond L2 per launch / launch time / 8 TB/s: an upper bound on the HBM share, "
+                                     "Infinity Cache hits are counted in it",
+                         "valu_issue_frac": pmc.get("valu_issue_frac_of_guide_peak") if pmc else None,
+                         "valu_lane_utilisation": pmc.get("valu_lane_utilisation") if pmc else None,
+                         "l2_hit_rate": pmc.get("l2_hit_rate") if pmc else None},
         }
+        if world == 1 and not args.no_call_granularity and pipeline == rt.PIPELINE_PERSISTENT:
+            result["call_granularity"] = call_granularity(r, ro, bounces, pipeline, args)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(rt, tris, nodes, sc.spheres(), cam, W, H, bounces, ro)
         else:

@@ -89,6 +89,20 @@ typedef struct RtStats {
                                reference's and that were traced again in the reference's order */
 } RtStats;
 
+/* How the library runs the uploaded scene (diagnostics; no counterpart in the reference). */
+typedef struct RtSceneInfo {
+    int64_t triangles;
+    int64_t index_nodes;            /* 4-wide nodes of the search index; 0 when the scene has none */
+    int32_t tree_height;            /* levels below the root of the reference tree */
+    int32_t index_stack_need;       /* bound on the deferred nodes of one search through the index */
+    int32_t index_stack_lds;        /* how many of them are kept in LDS; deeper ones use global memory */
+    int32_t index_enabled;          /* 0: the tree's boxes are not the exact nested min/max boxes the
+                                       proof step relies on (or the index was switched off), every
+                                       ray is traced in the reference's order */
+    int32_t paths_waves_per_simd;   /* variant of the persistent path kernel used for this scene: 5, 6 or 7 */
+    int32_t frames_per_launch;      /* most frames one launch of the path kernel renders at this image size */
+} RtSceneInfo;
+
 /* Render options; rt_default_options() gives the reference's behaviour. */
 typedef struct RtOptions {
     int32_t max_bounces;    /* loop bound of shading(), 4 in the reference (frag:624); <= 8 */
@@ -265,6 +279,7 @@ int rt_sum_device_ptr(RtContext *ctx, void **dev_ptr);
 int rt_bind_sum_buffer(RtContext *ctx, float *dev_ptr);
 
 int rt_get_stats(RtContext *ctx, RtStats *out);
+int rt_get_scene_info(RtContext *ctx, RtSceneInfo *out);
 /* Device time of the traversal ("extend") kernel launches since the last rt_reset, measured
  * with HIP events on the context's stream.  Synchronises. */
 int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches);
@@ -275,6 +290,19 @@ int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches);
  * tools. */
 int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64_t n,
                   float *t_out, int32_t *id_out);
+
+/* rt_trace_rays for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  d_origins/d_dirs
+ * (n*3 floats) and d_t_out/d_id_out (n values) are DEVICE pointers on the context's GPU.  The
+ * call allocates and frees nothing, on the host or on the device: its working memory (ray queue,
+ * hit records, queue counters; 8 words per ray) is a fixed array inside the library, one copy
+ * per GPU (8.4 MB, held until the process ends), which limits a call to RT_NOALLOC_MAX_RAYS
+ * rays; more is RT_E_INVALID.  Asynchronous on the context's stream (rt_synchronize waits).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two contexts on
+ * different streams or threads) race and must be serialised by the caller. */
+#define RT_NOALLOC_MAX_RAYS 262144
+int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d_dirs, int64_t n,
+                          float *d_t_out, int32_t *d_id_out);
 
 /* Diagnostics with no counterpart in the reference, used by the parity tests.
  * rt_selftest_nth_element: the builder's selection routine alone (keys with ids carried

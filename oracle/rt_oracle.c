@@ -610,4 +610,16 @@ int or_hit_bvh(const OrScene *sc, const float origin[3], const float dir[3], flo
     return h;
 }
 
+/* The same for n rays (origins/dirs: n*3 floats); t_out[i] = -1 and tri_out[i] = -1 on a miss.
+ * Parallel over rays with OpenMP. */
+void or_hit_bvh_many(const OrScene *sc, const float *origins, const float *dirs, long long n,
+                     float *t_out, int *tri_out) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long long i = 0; i < n; i++) {
+        float t = -1.0f; int tri = -1;
+        if (!or_hit_bvh(sc, origins + 3 * i, dirs + 3 * i, &t, &tri)) { t = -1.0f; tri = -1; }
+        t_out[i] = t; tri_out[i] = tri;
+    }
+}
+
 int or_is_fused(void) { return RT_ORACLE_FUSED; }

@@ -21,6 +21,7 @@ lib = C.CDLL(LIB_PATH)
 RT_MAX_SPHERES = 10
 RT_SOBOL_WORDS = 512
 RT_MAX_BOUNCES = 8
+RT_NOALLOC_MAX_RAYS = 262144
 PIPELINE_WAVEFRONT = 0
 PIPELINE_MEGAKERNEL = 1
 PIPELINE_PERSISTENT = 2
@@ -51,6 +52,12 @@ class RtCameraRig(C.Structure):
                 ("firstMouse", C.c_int32), ("lastX", C.c_float), ("lastY", C.c_float),
                 ("ScreenRatio", C.c_float), ("halfH", C.c_float), ("halfW", C.c_float),
                 ("LeftBottomCorner", C.c_float * 3), ("LoopNum", C.c_int32)]
+
+
+class RtSceneInfo(C.Structure):
+    _fields_ = [("triangles", C.c_int64), ("index_nodes", C.c_int64), ("tree_height", C.c_int32),
+                ("index_stack_need", C.c_int32), ("index_stack_lds", C.c_int32), ("index_enabled", C.c_int32),
+                ("paths_waves_per_simd", C.c_int32), ("frames_per_launch", C.c_int32)]
 
 
 class RtOptions(C.Structure):
@@ -110,6 +117,8 @@ _PROTOS = {
     "rt_get_stats": (_int, [_vp, C.POINTER(RtStats)]),
     "rt_get_kernel_time": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "rt_trace_rays": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "rt_trace_rays_noalloc": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "rt_get_scene_info": (_int, [_vp, C.POINTER(RtSceneInfo)]),
     "rt_selftest_nth_element": (_int, [_vp, _vp, _i64, _i64]),
     "rt_selftest_arith": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "rt_last_error": (C.c_char_p, [_vp]),
@@ -361,6 +370,16 @@ class Renderer:
         s = RtStats()
         _check(lib.rt_get_stats(self._h, C.byref(s)), self._h)
         return {k: getattr(s, k) for k, _ in RtStats._fields_}
+
+    def scene_info(self):
+        s = RtSceneInfo()
+        _check(lib.rt_get_scene_info(self._h, C.byref(s)), self._h)
+        return {k: getattr(s, k) for k, _ in RtSceneInfo._fields_}
+
+    def trace_rays_noalloc(self, d_origins, d_dirs, n, d_t_out, d_id_out):
+        """Device pointers (ints) in, device pointers out; asynchronous on the context's stream."""
+        _check(lib.rt_trace_rays_noalloc(self._h, C.c_void_p(d_origins), C.c_void_p(d_dirs), n,
+                                         C.c_void_p(d_t_out), C.c_void_p(d_id_out)), self._h)
 
     def kernel_time(self):
         ms, n = C.c_double(), C.c_int64()

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -52,6 +53,7 @@ __device__ __forceinline__ void flush_counters(WorkCounters *wc, uint32_t rays, 
 template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const FrameD F, const int firstLoopNum,
                                                       const int count, const float *__restrict__ randOrigin,
+                                                      const uint32_t *__restrict__ sobV,
                                                       float *__restrict__ sum, float *__restrict__ mean,
                                                       const int history8, WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_stack[];
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
                 cRays++;
                 if (COUNT && tri != REF_NONE) cHit++;
                 float su, sv;
-                sobol_pair(loopNum, (uint32_t)b, su, sv);
+                sobol_pair(sobV, loopNum, (uint32_t)b, su, sv);
                 if (!shade_hit(F, S, p, t, tri, b, su, sv, uvx, uvy, sample)) break;
             }
             // frag:697 with an fp32 history, and the plain sum
@@ -297,14 +299,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
 // shade: one thread per ray of the current queue; finished paths write their sample,
 // continuing paths are compacted into the next queue.
 __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F, const int bounce, const uint32_t loopNum,
-                                                 const PathSoA Qin, const uint32_t cap, const uint32_t *__restrict__ qcountIn,
+                                                 const uint32_t *__restrict__ sobV, const PathSoA Qin, const uint32_t cap, const uint32_t *__restrict__ qcountIn,
                                                  const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri,
                                                  const PathSoA Qout, uint32_t *__restrict__ qcountOut,
                                                  float *__restrict__ cur) {
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t total = NSHARD * cap;        // cap is a multiple of 64: a wave never straddles shards
     float su, sv;
-    sobol_pair(loopNum, (uint32_t)bounce, su, sv);
+    sobol_pair(sobV, loopNum, (uint32_t)bounce, su, sv);
     for (uint32_t v0 = blockIdx.x * BLOCK; v0 < total; v0 += stride) {
         const uint32_t v = v0 + threadIdx.x;
         const uint32_t shardIn = v / cap, idx = v - shardIn * cap;
@@ -367,7 +369,7 @@ constexpr int PATHS_MAX_FRAMES = 64;
 
 // Sobol numbers of every (frame slot, bounce) of a batch: they do not depend on the pixel
 // (frag:99-104).  table[(slot * maxBounces + bounce) * 2 + {0,1}].
-__global__ void k_sobol_table(const BatchD B, const int maxBounces, float *__restrict__ table) {
+__global__ void k_sobol_table(const BatchD B, const int maxBounces, const uint32_t *__restrict__ sobV, float *__restrict__ table) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B.nframes * maxBounces * 2) return;
     const int f = t / (maxBounces * 2), r = t - f * (maxBounces * 2);
@@ -375,7 +377,7 @@ __global__ void k_sobol_table(const BatchD B, const int maxBounces, float *__res
     uint32_t g = loopNum ^ (loopNum >> 1), acc = 0u;
     const uint32_t base = (uint32_t)(r >> 1) * 64u + (uint32_t)(r & 1) * 32u;
     for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
-        if (g & 1u) acc ^= c_sobolV[base + j];
+        if (g & 1u) acc ^= sobV[base + j];
     table[t] = (float)acc * (1.0f / 4294967296.0f);
 }
 
@@ -603,7 +605,39 @@ __global__ void k_selftest(const float *__restrict__ a, const float *__restrict_
     out[5 * i + 4] = c;
 }
 
+// Staging kernels of rt_trace_rays_noalloc: caller rays (n*3 floats each) into the queue layout
+// the extend kernels read, with the queue's control words cleared and shard 0 holding all n
+// rays; and the results back into the caller's arrays (-1 for a miss).
+__global__ __launch_bounds__(BLOCK) void k_stage_rays(const float *__restrict__ origins, const float *__restrict__ dirs, const uint32_t n,
+                                                     const uint32_t cap, float *__restrict__ soa, uint32_t *__restrict__ ctl, const uint32_t ctlWords) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < ctlWords) ctl[i] = (i == 0u) ? n : 0u;
+    if (i >= cap) return;
+    for (uint32_t c = 0; c < 3u; c++) {
+        soa[(size_t)c * cap + i] = (i < n) ? origins[3u * i + c] : 0.0f;
+        soa[(size_t)(3u + c) * cap + i] = (i < n) ? dirs[3u * i + c] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_unstage_hits(const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri, const uint32_t n,
+                                                       float *__restrict__ tOut, int32_t *__restrict__ idOut) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const bool hit = hitTri[i] != REF_NONE;
+    tOut[i] = hit ? hitT[i] : -1.0f;
+    idOut[i] = hit ? (int32_t)hitTri[i] : -1;
+}
+
 }  // namespace
+
+// Working memory of rt_trace_rays_noalloc, one copy per GPU the library runs on, held until the
+// process ends: the ray queue (6 words per ray), the hit records (2 words per ray) and the
+// queue's control words.  Host code never uses this name as an address: rt_create looks the
+// device address up once per device (hipGetSymbolAddress) and the entry point passes that
+// pointer to the kernels.
+constexpr uint32_t NOALLOC_CTL_WORDS = 2 * NSHARD * CTL_STRIDE;     // fill counts, then dequeue heads, of one sharded queue
+constexpr size_t NOALLOC_SCRATCH_WORDS = (size_t)8 * RT_NOALLOC_MAX_RAYS + NOALLOC_CTL_WORDS;
+static __device__ __align__(256) uint32_t scratch[NOALLOC_SCRATCH_WORDS];
 
 // ====================================================================== host side
 
@@ -618,14 +652,16 @@ struct RtContext {
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
     float4 *dANodes = nullptr; uint32_t *dAOvf = nullptr;      // search index: nodes, overflow of the deferred-node stack
     int accelLdsEntries = 16;
-    int64_t nTris = 0, nInterior = 0;
+    int64_t nTris = 0, nInterior = 0, nIndexNodes = 0;
+    int indexStackNeed = 0;
+    bool boxesExact = true;         // the uploaded boxes are the nested min/max boxes the proof step needs
     SceneD scene{};
     bool haveScene = false;
 
     FrameD frame{};
     bool haveCamera = false;
     uint32_t sobol[RT_SOBOL_WORDS];
-    bool sobolDirty = true;
+    uint32_t *dSobolV = nullptr;    // this context's direction numbers (setSobol, sobol.h:27-34)
 
     // images
     float *dSum = nullptr, *dSumOwned = nullptr, *dMean = nullptr, *dCur = nullptr;
@@ -638,7 +674,7 @@ struct RtContext {
     int extendBlocksPerCU = 7;
     float *dRandOrigin = nullptr; int randCap = 0;
     // persistent-path pipeline: one sample image per frame of a batch, and the item counter
-    float *dCurBatch = nullptr; int curBatchFrames = 0;
+    float *dCurBatch = nullptr; int curBatchFrames = 0;     // sample images allocated so far (grown on demand)
     float *dSobTable = nullptr;     // k_sobol_table output for one batch
     uint32_t *dWorkHead = nullptr;
     int pathsOcc = 0;           // waves per SIMD the path kernel is compiled for (5, 6 or 7); 0 = by scene size
@@ -654,6 +690,24 @@ struct RtContext {
 };
 
 namespace {
+
+// Device address of `scratch` on each GPU (every GPU holds its own copy at its own address).
+constexpr int MAX_DEVICES = 64;
+uint32_t *g_scratchPtr[MAX_DEVICES] = {};
+std::mutex g_scratchMutex;
+
+// Looks the address up once per device; `device` must be the current device.
+hipError_t lookup_scratch(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (g_scratchPtr[device]) return hipSuccess;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratchPtr[device] = (uint32_t *)p;
+    return hipSuccess;
+}
 
 int fail(RtContext *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -696,7 +750,8 @@ int resolve_events(RtContext *ctx) {
 // tree shape first so that a malformed tree is rejected on the host instead of faulting on the
 // GPU.
 int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtLinearBVHNode *nodes, int64_t m,
-                       std::vector<float4> &hNodes, std::vector<float4> &hTris, std::vector<float4> &hMats, SceneD &S) {
+                       std::vector<float4> &hNodes, std::vector<float4> &hTris, std::vector<float4> &hMats, SceneD &S,
+                       bool &boxesExact) {
     if (n <= 0 || m != 2 * n - 1) return fail(ctx, RT_E_INVALID, "scene upload: need n >= 1 triangles and exactly 2n-1 nodes");
     if (n > (int64_t)0x7FFFFFF0) return fail(ctx, RT_E_INVALID, "scene upload: too many triangles");
     std::vector<uint32_t> interiorIdx((size_t)m, REF_NONE);
@@ -723,6 +778,27 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
         }
     }
     if ((int64_t)nInterior != n - 1) return fail(ctx, RT_E_INVALID, "scene upload: tree does not have n-1 interior nodes");
+    // The search index proves its results with one test of the triangle's own min/max box
+    // (verify_reference_reaches), which stands for every box above it only when each leaf box
+    // IS that min/max box and each parent box contains its children (BVH.h:190-197 builds them
+    // so).  A tree with other boxes is still rendered, in the reference's order only.
+    boxesExact = true;
+    for (int64_t k = 0; k < m && boxesExact; k++) {
+        const RtLinearBVHNode &nd = nodes[k];
+        if (nd.triangleNum == 1) {
+            const RtTriangle &t = tris[nd.offsetOrRc];
+            for (int c = 0; c < 3; c++) {
+                const float lo = std::fmin(std::fmin(t.v[0][c], t.v[1][c]), t.v[2][c]);
+                const float hi = std::fmax(std::fmax(t.v[0][c], t.v[1][c]), t.v[2][c]);
+                if (!(nd.minBound[c] == lo) || !(nd.maxBound[c] == hi)) boxesExact = false;
+            }
+        } else {
+            const RtLinearBVHNode *ch[2] = {&nodes[k + 1], &nodes[nd.offsetOrRc]};
+            for (int s = 0; s < 2; s++)
+                for (int c = 0; c < 3; c++)
+                    if (!(nd.minBound[c] <= ch[s]->minBound[c]) || !(nd.maxBound[c] >= ch[s]->maxBound[c])) boxesExact = false;
+        }
+    }
     if (maxDepth > 60) return fail(ctx, RT_E_INVALID, "scene upload: tree deeper than 60 levels");
     auto ref_of = [&](int64_t k) -> uint32_t {
         return nodes[k].triangleNum == 1 ? (LEAF_BIT | (uint32_t)nodes[k].offsetOrRc) : interiorIdx[(size_t)k];
@@ -779,16 +855,24 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
     return RT_OK;
 }
 
-int ensure_sobol(RtContext *ctx) {
-    // the table is per device (one module per device); upload before every batch whose
-    // context last touched it is not this one
-    static thread_local const RtContext *lastOwner = nullptr;
-    if (ctx->sobolDirty || lastOwner != ctx) {
-        HIP_TRY(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sobolV), ctx->sobol, sizeof ctx->sobol, 0, hipMemcpyHostToDevice, ctx->stream));
-        ctx->sobolDirty = false;
-        lastOwner = ctx;
-    }
-    return RT_OK;
+// Most frames one launch of the path kernel may render at this image size.
+int paths_frames_cap(const RtContext *ctx) {
+    int bitsX = 1, bitsY = 1;
+    while ((1 << bitsX) < ctx->width) bitsX++;
+    while ((1 << bitsY) < ctx->height) bitsY++;
+    const size_t perFrame = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    const size_t tiles = (size_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
+    int g = (int)std::min<size_t>(PATHS_MAX_FRAMES, std::max<size_t>(1, ((size_t)2 << 30) / perFrame));
+    g = std::min(g, (int)std::min<uint32_t>(64u, 1u << (32 - bitsX - bitsY)));
+    g = (int)std::min<size_t>((size_t)g, std::max<size_t>(1, ((size_t)1 << 31) / (tiles * 64 + 1)));
+    if (const char *env = getenv("RT_AMD_BATCH_FRAMES")) { const int v = atoi(env); if (v >= 1 && v < g) g = v; }
+    return g;
+}
+
+int paths_occupancy(const RtContext *ctx) {
+    // Occupancy against spills: large scenes have more memory latency to hide (7 waves per
+    // SIMD, 16 spilled values), small ones spend their time in the finish block (6 waves, 7 spilled).
+    return ctx->pathsOcc ? std::min(std::max(ctx->pathsOcc, 5), 7) : (ctx->nTris >= 65536 ? 7 : 6);
 }
 
 size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
@@ -828,6 +912,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) ctx->numCU = prop.multiProcessorCount;
+    if (e == hipSuccess) e = lookup_scratch(device);
     const size_t img = (size_t)width * height * 3 * sizeof(float);
     // queue capacity: 8x8 tiles dealt round-robin to the shards
     const size_t tilesTotal = (size_t)((width + 7) / 8) * ((height + 7) / 8);
@@ -841,6 +926,8 @@ int rt_create(RtContext **out, int width, int height, int device) {
     if (e == hipSuccess) e = hipMalloc(&ctx->dHitTri, P * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->dQueueCtl, QCTL_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->dCounters, sizeof(WorkCounters));
+    if (e == hipSuccess) e = hipMalloc(&ctx->dSobolV, sizeof ctx->sobol);
+    if (e == hipSuccess) e = hipMemcpy(ctx->dSobolV, ctx->sobol, sizeof ctx->sobol, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         std::string msg = std::string("rt_create: ") + hipGetErrorString(e);
         rt_destroy(ctx);
@@ -883,7 +970,7 @@ void rt_destroy(RtContext *ctx) {
     hipFree(ctx->dANodes); hipFree(ctx->dAOvf);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
-    hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin);
+    hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin); hipFree(ctx->dSobolV);
     hipFree(ctx->dCurBatch); hipFree(ctx->dWorkHead); hipFree(ctx->dSobTable);
     delete ctx;
 }
@@ -908,12 +995,13 @@ int rt_set_options(RtContext *ctx, const RtOptions *opt) {
 int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtLinearBVHNode *nodes, int64_t m) {
     if (!ctx || !tris || !nodes) return fail(ctx, RT_E_INVALID, "rt_scene_upload: null pointer");
     std::vector<float4> hNodes, hTris, hMats; SceneD S;
-    int rc = build_device_scene(ctx, tris, n, nodes, m, hNodes, hTris, hMats, S);
+    bool boxesExact = true;
+    int rc = build_device_scene(ctx, tris, n, nodes, m, hNodes, hTris, hMats, S, boxesExact);
     if (rc != RT_OK) return rc;
     // search index for the extend stage (skipped when RT_AMD_NO_ACCEL is set)
     rt::Accel accel;
     bool haveAccel = false;
-    if (!getenv("RT_AMD_NO_ACCEL")) {
+    if (boxesExact && !getenv("RT_AMD_NO_ACCEL")) {
         const float maxAbs = S.cullEps * 1024.0f;
         if (rt::build_accel(tris, n, maxAbs, 1, accel) == RT_OK && accel.directLeaves && accel.wideStack <= 160) {
             haveAccel = true;
@@ -953,6 +1041,9 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         S.aovf = ctx->dAOvf;
     }
     ctx->scene = S; ctx->nTris = n; ctx->nInterior = n - 1; ctx->haveScene = true;
+    ctx->boxesExact = boxesExact;
+    ctx->nIndexNodes = haveAccel ? (int64_t)accel.wide.size() : 0;
+    ctx->indexStackNeed = haveAccel ? std::max(accel.wideStack, 1) : 0;
     return RT_OK;
 }
 
@@ -982,7 +1073,10 @@ int rt_scene_upload_textures(RtContext *ctx, const float *tex_triangle, int64_t 
 int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]) {
     if (!ctx || !v) return fail(ctx, RT_E_INVALID, "rt_set_sobol: null pointer");
     std::memcpy(ctx->sobol, v, sizeof ctx->sobol);
-    ctx->sobolDirty = true;
+    // stream ordered: frames already queued keep the old table
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dSobolV, ctx->sobol, sizeof ctx->sobol, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 
@@ -1027,8 +1121,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_render_frames: no scene uploaded");
     if (!ctx->haveCamera) return fail(ctx, RT_E_STATE, "rt_render_frames: no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_sobol(ctx);
-    if (rc != RT_OK) return rc;
+    int rc = RT_OK;
     if (ctx->pendingEvents.size() > 8192) { rc = resolve_events(ctx); if (rc != RT_OK) return rc; }
     const FrameD &F = ctx->frame;
     const SceneD &S = ctx->scene;
@@ -1051,7 +1144,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
         if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
         HIP_TRY(ctx, hipEventRecord(e0, st));
-#define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters)
+#define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters)
         if (cull) { if (cnt) LAUNCH_MEGA(true, true); else LAUNCH_MEGA(true, false); }
         else { if (cnt) LAUNCH_MEGA(false, true); else LAUNCH_MEGA(false, false); }
 #undef LAUNCH_MEGA
@@ -1067,36 +1160,34 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         int bitsX = 1, bitsY = 1;       // bits of the largest pixel coordinates
         while ((1 << bitsX) < ctx->width) bitsX++;
         while ((1 << bitsY) < ctx->height) bitsY++;
-        if (!ctx->dCurBatch) {
-            // frames per launch: up to 64, within 2 GiB of sample images, 2^31 items and the slot bits of the pixel word
-            const size_t perFrame = nfloats * sizeof(float);
-            int g = (int)std::min<size_t>(PATHS_MAX_FRAMES, std::max<size_t>(1, ((size_t)2 << 30) / perFrame));
-            g = std::min(g, (int)std::min<uint32_t>(64u, 1u << (32 - bitsX - bitsY)));
-            g = (int)std::min<size_t>((size_t)g, std::max<size_t>(1, ((size_t)1 << 31) / ((size_t)tiles * 64 + 1)));
-            if (const char *env = getenv("RT_AMD_BATCH_FRAMES")) { const int v = atoi(env); if (v >= 1 && v < g) g = v; }
-            HIP_TRY(ctx, hipMalloc(&ctx->dCurBatch, (size_t)g * perFrame));
-            ctx->curBatchFrames = g;
+        // frames per launch: up to 64, within 2 GiB of sample images, 2^31 items and the slot bits of
+        // the pixel word; the sample images are allocated for the largest call seen so far
+        const int cap = paths_frames_cap(ctx);
+        const int wantFrames = std::min(count, cap);
+        if (wantFrames > ctx->curBatchFrames) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            hipFree(ctx->dCurBatch); ctx->dCurBatch = nullptr; ctx->curBatchFrames = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dCurBatch, (size_t)wantFrames * nfloats * sizeof(float)));
+            ctx->curBatchFrames = wantFrames;
         }
         if (!ctx->dWorkHead) HIP_TRY(ctx, hipMalloc(&ctx->dWorkHead, 128));
         if (!ctx->dSobTable) HIP_TRY(ctx, hipMalloc(&ctx->dSobTable, (size_t)PATHS_MAX_FRAMES * RT_MAX_BOUNCES * 2 * sizeof(float)));
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
-        // Occupancy against spills: large scenes have more memory latency to hide (7 waves per
-        // SIMD, 16 spilled values), small ones spend their time in the finish block (6 waves, 7 spilled).
-        const int occ = ctx->pathsOcc ? std::min(std::max(ctx->pathsOcc, 5), 7) : (ctx->nTris >= 65536 ? 7 : 6);
+        const int occ = paths_occupancy(ctx);
         const int blocks = ctx->numCU * (fast ? occ : 5);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
         SceneD Sp = S;
         Sp.leafBatch = ctx->pathsLeafBatch;
-        for (int off = 0; off < count; off += ctx->curBatchFrames) {
+        for (int off = 0; off < count; off += cap) {
             BatchD B;
             B.firstLoopNum = first_loopnum + off;
-            B.nframes = std::min(ctx->curBatchFrames, count - off);
+            B.nframes = std::min(cap, count - off);
             B.bitsX = bitsX; B.bitsY = bitsY;
             for (int f = 0; f < PATHS_MAX_FRAMES; f++) B.randOrigin[f] = f < B.nframes ? rand_origin[off + f] : 0.0f;
             const size_t ldsP = fast ? fast_stack_bytes(ctx) : lds;
             const int sobWords = B.nframes * F.maxBounces * 2;
-            hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, st, B, F.maxBounces, ctx->dSobTable);
+            hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, st, B, F.maxBounces, ctx->dSobolV, ctx->dSobTable);
             HIP_TRY(ctx, hipMemsetAsync(ctx->dWorkHead, 0, sizeof(uint32_t), st));
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
@@ -1152,7 +1243,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             }
             HIP_TRY(ctx, hipEventRecord(e1, st));
             ctx->pendingEvents.emplace_back(e0, e1);
-            hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, qin, cap, counts + b * qstride,
+            hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
                                ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
         }
         hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum,
@@ -1217,6 +1308,21 @@ int rt_get_stats(RtContext *ctx, RtStats *out) {
     return RT_OK;
 }
 
+int rt_get_scene_info(RtContext *ctx, RtSceneInfo *out) {
+    if (!ctx || !out) return fail(ctx, RT_E_INVALID, "rt_get_scene_info: null pointer");
+    if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_get_scene_info: no scene uploaded");
+    std::memset(out, 0, sizeof *out);
+    out->triangles = ctx->nTris;
+    out->index_nodes = ctx->nIndexNodes;
+    out->tree_height = ctx->scene.stackEntries - 1;
+    out->index_stack_need = ctx->indexStackNeed;
+    out->index_stack_lds = ctx->scene.anodes ? ctx->scene.aldsEntries : 0;
+    out->index_enabled = ctx->scene.anodes != nullptr;
+    out->paths_waves_per_simd = (ctx->opt.accel != 0 && ctx->scene.anodes) ? paths_occupancy(ctx) : 5;
+    out->frames_per_launch = paths_frames_cap(ctx);
+    return RT_OK;
+}
+
 int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches) {
     if (!ctx || !total_ms || !launches) return fail(ctx, RT_E_INVALID, "rt_get_kernel_time: null pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1277,6 +1383,44 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64
         t_out[i] = hit ? hT[(size_t)i] : -1.0f;
         id_out[i] = hit ? (int32_t)hI[(size_t)i] : -1;
     }
+    return RT_OK;
+}
+
+// rt_trace_rays for callers that cannot allocate.  Rays and results are device arrays of the
+// caller; everything in between lives in this GPU's `scratch` array, reached through the pointer
+// rt_create looked up.  Nothing here allocates or frees, on the host or on the device, and the
+// call does not wait for the GPU.
+int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d_dirs, int64_t n, float *d_t_out, int32_t *d_id_out) {
+    if (!ctx || !d_origins || !d_dirs || !d_t_out || !d_id_out || n < 0) return fail(ctx, RT_E_INVALID, "rt_trace_rays_noalloc: bad argument");
+    if (n > (int64_t)RT_NOALLOC_MAX_RAYS) return fail(ctx, RT_E_INVALID, "rt_trace_rays_noalloc: more than RT_NOALLOC_MAX_RAYS (262144) rays per call");
+    if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_trace_rays_noalloc: no scene uploaded");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t *base = (ctx->device >= 0 && ctx->device < MAX_DEVICES) ? g_scratchPtr[ctx->device] : nullptr;
+    if (!base) return fail(ctx, RT_E_STATE, "rt_trace_rays_noalloc: working memory of this device was not initialised");
+    const uint32_t cap = (uint32_t)((n + 63) / 64 * 64);
+    float *soa = (float *)base;                                     // 6 * cap words
+    float *hitT = (float *)(base + (size_t)6 * RT_NOALLOC_MAX_RAYS);
+    uint32_t *hitTri = base + (size_t)7 * RT_NOALLOC_MAX_RAYS;
+    uint32_t *ctl = base + (size_t)8 * RT_NOALLOC_MAX_RAYS;         // cleared by k_stage_rays on every call
+    uint32_t *counts = ctl, *heads = ctl + NSHARD * CTL_STRIDE;
+    PathSoA q{};
+    q.ox = soa; q.oy = soa + cap; q.oz = soa + 2 * (size_t)cap;
+    q.dx = soa + 3 * (size_t)cap; q.dy = soa + 4 * (size_t)cap; q.dz = soa + 5 * (size_t)cap;
+    const SceneD &S = ctx->scene;
+    hipStream_t st = ctx->stream;
+    const int stageBlocks = (int)((std::max<uint32_t>(cap, NOALLOC_CTL_WORDS) + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_stage_rays, dim3(stageBlocks), dim3(BLOCK), 0, st, d_origins, d_dirs, (uint32_t)n, cap, soa, ctl, NOALLOC_CTL_WORDS);
+    const int blocks = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)ctx->numCU * ctx->extendBlocksPerCU);
+    if (ctx->opt.accel != 0 && S.anodes != nullptr) {
+        hipLaunchKernelGGL((k_extend_fast<false>), dim3(blocks), dim3(BLOCK), fast_stack_bytes(ctx), st, S, q, cap, counts, heads, hitT, hitTri, ctx->dCounters);
+    } else if (ctx->opt.cull) {
+        hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(BLOCK), stack_bytes(ctx), st, S, q, cap, counts, heads, hitT, hitTri, ctx->dCounters);
+    } else {
+        hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(BLOCK), stack_bytes(ctx), st, S, q, cap, counts, heads, hitT, hitTri, ctx->dCounters);
+    }
+    hipLaunchKernelGGL(k_unstage_hits, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, hitT, hitTri, (uint32_t)n, d_t_out, d_id_out);
+    HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
 

@@ -9,10 +9,6 @@
 #include "rt_kernels.h"
 #include "rt_traverse.h"
 
-// Sobol direction numbers (uniform uint V[512], frag:81) live in constant memory: every lane
-// of a wave reads the same word, which the scalar unit serves.
-__constant__ uint32_t c_sobolV[RT_SOBOL_WORDS];
-
 namespace rtd {
 
 __device__ __forceinline__ float rand01(uint32_t &wseed) {     // frag:36-47
@@ -20,16 +16,17 @@ __device__ __forceinline__ float rand01(uint32_t &wseed) {     // frag:36-47
     return (float)wseed * (1.0f / 4294967296.0f);
 }
 
-// frag:84-104 for one bounce: dims 2b and 2b+1 of frame `loopNum`.  loopNum and b are wave
-// uniform, so this runs on the scalar unit out of constant memory.
-__device__ __forceinline__ void sobol_pair(uint32_t loopNum, uint32_t b, float &u, float &v) {
+// frag:84-104 for one bounce: dims 2b and 2b+1 of frame `loopNum`.  V is the context's copy of
+// the direction numbers (uniform uint V[512], frag:81), read-only device memory; loopNum and b
+// are wave uniform, so the words come through the scalar unit's constant cache.
+__device__ __forceinline__ void sobol_pair(const uint32_t *__restrict__ V, uint32_t loopNum, uint32_t b, float &u, float &v) {
     uint32_t g = loopNum ^ (loopNum >> 1);
     uint32_t r0 = 0u, r1 = 0u;
     const uint32_t base = b * 64u;
     for (uint32_t j = 0u; g != 0u; g >>= 1, j++)
         if (g & 1u) {
-            r0 ^= c_sobolV[base + j];
-            r1 ^= c_sobolV[base + 32u + j];
+            r0 ^= V[base + j];
+            r1 ^= V[base + 32u + j];
         }
     u = (float)r0 * (1.0f / 4294967296.0f);
     v = (float)r1 * (1.0f / 4294967296.0f);

@@ -82,6 +82,8 @@ def load(fused=True):
     lib.or_render_frame.argtypes = [C.POINTER(OrScene), C.POINTER(OrCamera), C.c_float, vp, vp, vp, i, i, vp]
     lib.or_hit_bvh.restype = i
     lib.or_hit_bvh.argtypes = [C.POINTER(OrScene), vp, vp, C.POINTER(C.c_float), C.POINTER(i)]
+    lib.or_hit_bvh_many.restype = None
+    lib.or_hit_bvh_many.argtypes = [C.POINTER(OrScene), vp, vp, C.c_longlong, vp, vp]
     lib.or_is_fused.restype = i
     _cache[name] = lib
     return lib
@@ -192,10 +194,7 @@ class OracleScene:
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
         t = np.full(o.shape[0], -1.0, dtype=np.float32)
         ids = np.full(o.shape[0], -1, dtype=np.int32)
-        tt, ii = C.c_float(), C.c_int()
-        for k in range(o.shape[0]):
-            if self.lib.or_hit_bvh(C.byref(self.s), _ptr(o[k]), _ptr(d[k]), C.byref(tt), C.byref(ii)):
-                t[k], ids[k] = tt.value, ii.value
+        self.lib.or_hit_bvh_many(C.byref(self.s), _ptr(o), _ptr(d), o.shape[0], _ptr(t), _ptr(ids))
         return t, ids
 
 

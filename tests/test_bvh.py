@@ -73,6 +73,26 @@ def test_builder_equals_oracle_synthetic_mesh():
     assert _same(a_n, b_n) and _same(a_t, b_t)
 
 
+@pytest.mark.parametrize("kind,level,copies,count", [(0, 8, 1, 1310740), (1, 64, 1, 262164), (0, 8, 8, 10485780)])
+def test_builder_equals_oracle_at_benchmark_sizes(kind, level, copies, count):
+    """The three benchmark scenes at full size: ranges above 65536 triangles are split on worker
+    threads in the library's builder (the oracle is the plain recursion of BVH.h:188-264); the
+    trees and the permuted triangle arrays must still be byte-equal."""
+    sc = rt.Scene()
+    sc.push_synthetic(kind, level, copies, 12345)
+    tris0 = sc.triangles()
+    del sc
+    assert tris0.shape[0] == count
+    a_t, a_n = rt.bvh_build(tris0)
+    b_t, b_n = ol.bvh_build(tris0)
+    assert a_n.shape[0] == 2 * count - 1
+    assert _same(a_n, b_n)
+    assert _same(a_t, b_t)
+    # shape facts the device layout relies on: median split => height ceil(log2 n), leaves in order
+    leaves = a_n[a_n["triangleNum"] == 1]
+    assert np.array_equal(leaves["offsetOrRc"], np.arange(count, dtype=np.int32))
+
+
 def _killer(n):
     """Median-of-3 killer sequence (Musser): drives introselect into its heap-select fallback."""
     k = n // 2

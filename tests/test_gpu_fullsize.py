@@ -1,0 +1,193 @@
+"""GPU parity at the benchmark sizes: the three synthetic workloads of bench.py at their full
+triangle counts and resolutions, i.e. the kernel variant, tree depth, stack overflow path and
+frame batching that the benchmark actually runs.
+
+The oracle is too slow for every pixel of these images, so each scene is checked through
+  (i)   a 16-row band of two consecutive frames, bit for bit against the oracle's rows;
+  (ii)  50 000 rays (random, axis-parallel, starting inside the mesh, starting far outside):
+        triangle index and distance equal to the oracle's hitBVH;
+  (iii) the whole image and the ray count of the default path (search index + proof) equal to
+        those of the reference-order traversal of the same kernel family;
+  (iv)  the share of rays that needed the exact re-trace;
+  (v)   the kernel variant (waves per SIMD) and the stack split the scene was given."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import raytracing_amd as rt
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+# name: (kind, level, copies, width, height, bounces, band of rows) -- as bench.py's WORKLOADS
+CASES = {
+    "dragon1m": (0, 8, 1, 1920, 1080, 4, (520, 536)),
+    "sponza": (1, 64, 1, 3840, 2160, 4, (700, 716)),
+    "stress10m": (0, 8, 8, 1920, 1080, 8, (500, 516)),
+}
+
+
+def _rays_for(tris, seed, n=50000):
+    rng = np.random.default_rng(seed)
+    lo = tris["v"].reshape(-1, 3).min(axis=0)
+    hi = tris["v"].reshape(-1, 3).max(axis=0)
+    o, d = scenes.random_rays(n, seed, extent=1.0, axis_aligned_fraction=0.1)
+    o = (lo + (o * 0.5 + 0.5) * (hi - lo)).astype(np.float32)
+    # a quarter of the rays start at the centre of a mesh triangle, pushed along a random direction
+    # by a small step: inside or just outside the surface
+    k = n // 4
+    pick = rng.integers(0, tris.shape[0], size=k)
+    c = tris["v"][pick].mean(axis=1)
+    o[n - k:] = (c + d[n - k:] * rng.uniform(-0.05, 0.05, size=(k, 1))).astype(np.float32)
+    # some start far outside the scene (the index hands those to the exact path)
+    o[n // 2:n // 2 + 500] *= np.float32(50.0)
+    return o, d
+
+
+@pytest.mark.parametrize("name", ["dragon1m", "sponza", "stress10m"])
+def test_benchmark_workload_at_full_size(name):
+    kind, level, copies, W, H, bounces, band = CASES[name]
+    sc = rt.Scene()
+    sc.push_synthetic(kind, level, copies, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    sph = sc.spheres()
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 2)
+    osc = ol.scene_from_build(tris, nodes, W, H, rt.sobol_default_table(), sph, max_bounces=bounces)
+
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    r.set_spheres(sph)
+    r.set_camera(cam)
+    r.set_options(max_bounces=bounces)                      # defaults: persistent pipeline, search index
+    info = r.scene_info()
+    # (v) what the benchmark runs: the 7-wave variant, an index deeper than its LDS stack
+    assert info["triangles"] == tris.shape[0] >= 65536
+    assert info["index_enabled"] == 1 and info["paths_waves_per_simd"] == 7
+    assert info["index_stack_need"] > info["index_stack_lds"] > 0
+    assert info["tree_height"] >= 18
+
+    # (ii) rays
+    o, d = _rays_for(tris, 5 + len(name))
+    t_want, id_want = osc.hit_bvh(o, d)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, id_want)
+    assert np.array_equal(t, t_want)
+    assert 0.3 < (id_want >= 0).mean()
+
+    # (i) + (iii): two frames through the default path
+    r.render(1, ro)
+    img = r.read_mean()
+    s = r.stats()
+    assert s["frames"] == 2
+    hist = np.zeros((H, W, 3), dtype=np.float32)
+    for k in range(2):
+        hist, _, _ = osc.render_frame(cam, k + 1, float(ro[k]), hist, rows=band)
+    y0, y1 = band
+    assert np.array_equal(np.isnan(img[y0:y1]), np.isnan(hist[y0:y1]))
+    m = ~np.isnan(hist[y0:y1])
+    assert np.array_equal(img[y0:y1][m], hist[y0:y1][m])
+    assert np.nan_to_num(hist[y0:y1]).max() > 0
+    # (iv)
+    assert s["retraced"] <= 1e-4 * s["rays"], (s["retraced"], s["rays"])
+
+    r.set_options(max_bounces=bounces, accel=False)         # the reference's tree in the reference's order
+    r.reset()
+    r.render(1, ro)
+    img_ref = r.read_mean()
+    s_ref = r.stats()
+    assert s_ref["rays"] == s["rays"] and s_ref["retraced"] == 0
+    assert np.array_equal(np.isnan(img), np.isnan(img_ref))
+    m = ~np.isnan(img_ref)
+    assert np.array_equal(img[m], img_ref[m])
+    r.close()
+
+
+def test_index_stack_overflow_and_small_lds_stack(monkeypatch):
+    """The deferred-node stack of the index search keeps its first entries in LDS and the rest in
+    a global column.  With only two LDS entries every deep traversal overflows; results must not
+    change (random scene with heavy overlap, so that many nodes are deferred)."""
+    monkeypatch.setenv("RT_AMD_ACCEL_LDS_ENTRIES", "2")
+    tris0 = scenes.random_triangles(6000, 31, extent=3.0, size=2.5)
+    tris, nodes = rt.bvh_build(tris0)
+    osc = ol.scene_from_build(tris, nodes, 64, 48, rt.sobol_default_table(), None)
+    r = rt.Renderer(64, 48)
+    r.upload(tris, nodes)
+    info = r.scene_info()
+    assert info["index_stack_lds"] == 2 and info["index_stack_need"] > 2
+    o, d = scenes.random_rays(20000, 3, extent=3.0)
+    t_want, id_want = osc.hit_bvh(o, d)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, id_want) and np.array_equal(t, t_want)
+    cam = rt.camera_from_angles((0.0, 0.0, 7.0), -90.0, 0.0, 30.0, 64, 48)
+    ro = rt.rand_origins(8, 2)
+    want, st = osc.render(cam, 1, ro, want_stats=True)
+    for pipeline in (rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT):
+        r.set_options(pipeline=pipeline)
+        r.set_camera(cam)
+        r.reset()
+        r.render(1, ro)
+        got = r.read_mean()
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        m = ~np.isnan(want)
+        assert np.array_equal(got[m], want[m])
+        assert r.stats()["rays"] == st["rays"]
+    r.close()
+
+
+def test_tree_with_foreign_boxes_is_rendered_in_reference_order():
+    """A caller may upload a tree whose boxes are not the builder's (looser boxes here).  The
+    proof step of the index relies on exact nested min/max boxes, so such a scene must fall back
+    to the reference-order traversal and still match the oracle run on the same tree."""
+    tris0 = scenes.random_triangles(500, 12, extent=3.0, size=1.0)
+    tris, nodes = rt.bvh_build(tris0)
+    loose = nodes.copy()
+    loose["minBound"] -= np.float32(0.25)
+    loose["maxBound"] += np.float32(0.25)
+    osc = ol.scene_from_build(tris, loose, 64, 48, rt.sobol_default_table(), None)
+    r = rt.Renderer(64, 48)
+    r.upload(tris, loose)
+    assert r.scene_info()["index_enabled"] == 0
+    o, d = scenes.random_rays(10000, 4, extent=4.0)
+    t_want, id_want = osc.hit_bvh(o, d)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, id_want) and np.array_equal(t, t_want)
+    # a box that does not contain its child: also no index
+    broken = nodes.copy()
+    k = int(np.nonzero(nodes["triangleNum"] > 4)[0][1])
+    broken["maxBound"][k] = broken["minBound"][k]
+    r.upload(tris, broken)
+    assert r.scene_info()["index_enabled"] == 0
+    osc2 = ol.scene_from_build(tris, broken, 64, 48, rt.sobol_default_table(), None)
+    t_want, id_want = osc2.hit_bvh(o, d)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, id_want) and np.array_equal(t, t_want)
+    r.upload(tris, nodes)
+    assert r.scene_info()["index_enabled"] == 1
+    r.close()
+
+
+def test_two_contexts_with_different_sobol_tables():
+    """setSobol is per context: two contexts on one GPU with different direction numbers,
+    rendered alternately, each match the oracle run with their own table."""
+    W, H = 96, 64
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(77, 4)
+    va = rt.sobol_default_table()
+    vb = (va * np.uint32(2654435761) + np.uint32(12345)).astype(np.uint32)     # any other table
+    want = {}
+    for key, v in (("a", va), ("b", vb)):
+        want[key], _ = ol.scene_from_build(tris, nodes, W, H, v, sc.spheres()).render(cam, 1, ro)
+    assert not np.array_equal(want["a"], want["b"])
+    for pipeline in (rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL):
+        ra = rt.make_renderer(sc, W, H, pipeline=pipeline)
+        rb = rt.make_renderer(sc, W, H, pipeline=pipeline)
+        rb.set_sobol(vb)
+        for k in range(len(ro)):                            # interleaved, one frame at a time
+            ra.render(k + 1, ro[k:k + 1])
+            rb.render(k + 1, ro[k:k + 1])
+        assert np.array_equal(ra.read_mean(), want["a"]), pipeline
+        assert np.array_equal(rb.read_mean(), want["b"]), pipeline
+        ra.close(); rb.close()

@@ -528,6 +528,60 @@ def test_full_size_properties_1080p():
     assert np.array_equal(imgs["wf_accel"][500:516], hist[500:516])
 
 
+def test_render_from_loaded_obj_files_with_reference_camera(golden_dir, tmp_path):
+    """main.cpp:103-110 end to end: the reference's own room.obj / cube.obj through the OBJ/MTL
+    loader, its two spheres, and the camera exactly as Camera.h:18-46 computes it (front.x =
+    cos(radians(-90)) is 4.4e-8 there, not 0: rt_camera_default's axis-aligned frame is an
+    idealisation), against the oracle; plus a multi-material OBJ with a group split."""
+    import os
+    W, H = 150, 100                                         # the reference's 1200x800 aspect
+    sc = rt.Scene()
+    sc.push_obj(os.path.join(golden_dir, "objects", "room.obj"), (5.0, 5.0, 5.0), (0.0, 5.0, 0.0))
+    sc.push_obj(os.path.join(golden_dir, "objects", "cube.obj"), (0.5, 5.0, -1.0), (0.0, 1.0, -2.0))
+    sc.push_sphere((0.0, 2.0, 1.0), 1.5, (0.9, 0.9, 0.9), 0.0, 0.0)
+    sc.push_sphere((-3.0, 2.0, 1.0), 1.5, (0.2, 0.2, 0.9), 0.0, 1.0)
+    rig = rt.CameraRig(W, H)
+    cam = rig.uniforms()
+    assert cam[0]["front"][0] != 0.0 and abs(cam[0]["front"][0]) < 1e-6     # not the idealised frame
+    ro = rt.rand_origins(20221003, 3)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    want, st = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro, want_stats=True)
+    res = _render_all_pipelines(tris, nodes, cam, ro, W, H, spheres=sc.spheres())
+    for name, (img, rays) in res.items():
+        assert _same_image(img, want), name
+        assert rays == st["rays"], name
+    assert np.nan_to_num(want).max() > 1.0
+    # the camera after some interaction (mouse look, zoom, a step forward): LoopNum restarts at 1
+    rig.update_front(600.0, 400.0); rig.update_front(640.0, 380.0)
+    rig.update_fov(3.0)
+    rig.process_keyboard(rt.CameraRig.FORWARD, 0.1)
+    cam2 = rig.uniforms()
+    assert not np.array_equal(cam2[0]["front"], cam[0]["front"])
+    want2, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam2, 1, ro[:2])
+    res2 = _render_all_pipelines(tris, nodes, cam2, ro[:2], W, H, spheres=sc.spheres())
+    for name, (img, _) in res2.items():
+        assert _same_image(img, want2), name
+
+    # a second model: several materials in one object, a group split, a light of its own
+    (tmp_path / "m.mtl").write_text("newmtl lamp\nKa 1 1 1\nKd 0 0 0\nKs 0 0 0\n\nnewmtl mirror\nKd 1 1 1\nKs 0 1 0\n\n"
+                                    "newmtl glass\nKd 1 1 1\nKs 0 0 0\n\nnewmtl half\nKd 0.7 0.6 0.5\nKs 0.5 0.8 0\n")
+    (tmp_path / "m.obj").write_text(
+        "mtllib m.mtl\nv -3 0 -4\nv 3 0 -4\nv 3 5 -4\nv -3 5 -4\nv -3 0 2\nv 3 0 2\nv 3 5 2\nv -3 5 2\n"
+        "o box\nusemtl half\nf 1 2 3 4\nf 1 2 6 5\nusemtl mirror\nf 2 3 7 6\nusemtl glass\nf 1 4 8 5\n"
+        "g top\nusemtl lamp\nf 4 3 7 8\n")
+    sc3 = rt.Scene()
+    sc3.push_obj(str(tmp_path / "m.obj"), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    assert sc3.triangles().shape[0] == 10
+    tris3, nodes3 = rt.bvh_build(sc3.triangles())
+    cam3 = rt.camera_from_angles((0.2, 2.0, 6.0), -92.0, 2.0, 35.0, W, H)
+    want3, st3 = _oracle_for(tris3, nodes3, W, H, None).render(cam3, 1, ro, want_stats=True)
+    res3 = _render_all_pipelines(tris3, nodes3, cam3, ro, W, H)
+    for name, (img, rays) in res3.items():
+        assert _same_image(img, want3), name
+        assert rays == st3["rays"], name
+    assert np.nan_to_num(want3).max() > 1.0
+
+
 def test_error_paths():
     r = rt.Renderer(16, 16)
     ro = rt.rand_origins(1, 1)

@@ -82,6 +82,42 @@ def test_polygon_fan_and_negative_indices(tmp_path):
     assert np.allclose(t[0]["kd"], 0.6)     # no material: loader default
 
 
+def test_material_and_group_splitting(tmp_path):
+    """One mesh per object/group statement and per change of material inside it, in file order,
+    each carrying its own Ka/Kd/Ks (Model.h:158-165 reads them per mesh); an empty group and a
+    repeated `usemtl` of the same name start nothing; a material that is not in the library gives
+    the loader default."""
+    (tmp_path / "two.mtl").write_text(
+        "newmtl red\nKa 0 0 0\nKd 0.9 0.1 0.1\nKs 1 1 0\n\n"
+        "newmtl glow\nKa 2 2 2\nKd 0 0 0\nKs 0 0 0\n\n"
+        "newmtl glass\nKd 1 1 1\nKs 0 0 0.5\n")
+    (tmp_path / "two.obj").write_text(
+        "mtllib two.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nv 1 0 1\nv 1 1 1\nv 0 1 1\n"
+        "o body\n"
+        "usemtl red\nf 1 2 3\nusemtl red\nf 1 3 4\n"        # same material again: still one mesh
+        "usemtl glow\nf 5 6 7\n"                              # second material inside the object
+        "g empty\n"                                            # a group without faces leaves no mesh
+        "g lid\nusemtl glass\nf 5 7 8\nf 1 2 6 5\n"         # group split; a quad -> 2 triangles
+        "usemtl nosuch\nf 2 3 7\n")
+    sc = rt.Scene()
+    sc.push_obj(str(tmp_path / "two.obj"), (2.0, 2.0, 2.0), (0.0, 0.0, -1.0))
+    t = sc.triangles()
+    assert t.shape[0] == 7
+    kd = t["kd"].astype(np.float64).round(4).tolist()
+    assert kd[0] == kd[1] == [0.9, 0.1, 0.1] and t["ks"][0].tolist() == [1.0, 1.0, 0.0]
+    assert t["ka"][2].tolist() == [2.0, 2.0, 2.0] and kd[2] == [0.0, 0.0, 0.0]
+    assert kd[3] == kd[4] == kd[5] == [1.0, 1.0, 1.0] and t["ks"][3].tolist() == [0.0, 0.0, 0.5]
+    assert t["ka"][3].tolist() == [0.0, 0.0, 0.0]                   # Ka absent in the library: zero
+    assert np.allclose(t["kd"][6], 0.6) and t["ks"][6].tolist() == [0.0, 0.0, 0.0]
+    # file order of faces is kept across the splits; scale then translate
+    assert t["v"][2].tolist() == [[0, 0, 1], [2, 0, 1], [2, 2, 1]]
+    assert t["v"][4].tolist() == [[0, 0, -1], [2, 0, -1], [2, 0, 1]] and t["v"][5].tolist() == [[0, 0, -1], [2, 0, 1], [0, 0, 1]]
+    # the same triangles go through the builder like any others
+    tris, nodes = rt.bvh_build(t)
+    assert nodes.shape[0] == 13 and sorted(tris["kd"].astype(np.float64).round(4).tolist()) == sorted(kd)
+
+
 def test_synthetic_scenes():
     sc = rt.Scene()
     sc.push_synthetic(0, 2, 1, 12345)
