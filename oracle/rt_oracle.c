@@ -91,6 +91,12 @@ typedef struct {
     int sphereNum;              /* frag:144 */
     int maxBounces;             /* 4 in the reference (frag:624) */
     int trigMode;               /* see ARITHMETIC CONTRACT */
+    const int32_t *bvhInts;     /* NULL, or 3 ints per node (triangleNum, offsetOrRc, axis) that replace
+                                   the float-encoded ones of texBVH.  The reference stores node indices
+                                   as floats (ObjectTexture.h:152-154) and recovers them with
+                                   int(f + 0.5) (frag:180-182), exact only below 2^23: it cannot express
+                                   a tree of more than 4 194 304 triangles.  Callers set this for such
+                                   trees only; everything else is read from the textures as usual. */
 } OrScene;
 
 typedef struct {
@@ -242,6 +248,11 @@ static Node get_node(const OrScene *sc, int offset) {
     n.triangleNum = (int)(At(sc->texBVH, sc->texBVHWidth, o + 6) + 0.5f);
     n.offsetOrRc = (int)(At(sc->texBVH, sc->texBVHWidth, o + 7) + 0.5f);
     n.axis = (int)(At(sc->texBVH, sc->texBVHWidth, o + 8) + 0.5f);
+    if (sc->bvhInts) {          /* tree beyond the float encoding's range, see OrScene */
+        n.triangleNum = sc->bvhInts[3 * (size_t)offset];
+        n.offsetOrRc = sc->bvhInts[3 * (size_t)offset + 1];
+        n.axis = sc->bvhInts[3 * (size_t)offset + 2];
+    }
     return n;
 }
 

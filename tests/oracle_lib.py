@@ -15,6 +15,12 @@ NODE_DTYPE = np.dtype([("minBound", "<f4", 3), ("maxBound", "<f4", 3),
                        ("triangleNum", "<i4"), ("offsetOrRc", "<i4"), ("axis", "<i4")])
 
 
+# Node indices below this survive the reference's float encoding: stored as floats
+# (ObjectTexture.h:152-154) and recovered with int(f + 0.5) (frag:180-182); from 2^23 on, f + 0.5 is
+# a tie that rounds to even, so odd indices come back one too large.
+FLOAT_EXACT_INTS = 1 << 23
+
+
 class OrCamera(C.Structure):
     _fields_ = [("camPos", C.c_float * 3), ("front", C.c_float * 3), ("right", C.c_float * 3),
                 ("up", C.c_float * 3), ("halfH", C.c_float), ("halfW", C.c_float),
@@ -33,7 +39,7 @@ class OrScene(C.Structure):
                 ("width", C.c_int), ("height", C.c_int),
                 ("V", C.c_void_p),
                 ("sphere", OrSphere * 10), ("sphereNum", C.c_int),
-                ("maxBounces", C.c_int), ("trigMode", C.c_int)]
+                ("maxBounces", C.c_int), ("trigMode", C.c_int), ("bvhInts", C.c_void_p)]
 
 
 class OrStats(C.Structure):
@@ -120,7 +126,7 @@ class OracleScene:
     """Holds the reference-format textures and uniforms for the shader oracle."""
 
     def __init__(self, tex_tri, tex_tri_w, ntri, tex_bvh, tex_bvh_w, nnode, width, height,
-                 sobol_v, spheres=None, max_bounces=4, trig_mode=1, fused=True):
+                 sobol_v, spheres=None, max_bounces=4, trig_mode=1, fused=True, bvh_ints=None):
         self.lib = load(fused)
         self._tt = np.ascontiguousarray(tex_tri, dtype=np.float32)
         self._tb = np.ascontiguousarray(tex_bvh, dtype=np.float32)
@@ -147,6 +153,8 @@ class OracleScene:
                 o.roughness = float(sp["roughness"])
         s.maxBounces = max_bounces
         s.trigMode = trig_mode
+        self._ints = None if bvh_ints is None else np.ascontiguousarray(bvh_ints, dtype=np.int32)
+        s.bvhInts = None if self._ints is None else self._ints.ctypes.data
         self.s = s
         self.width, self.height = width, height
 
@@ -201,4 +209,9 @@ class OracleScene:
 def scene_from_build(tris, nodes, width, height, sobol_v, spheres=None, **kw):
     """Oracle scene from builder output (either the oracle's or the library's arrays)."""
     tt, tw, tb, bw = pack_textures(tris, nodes)
-    return OracleScene(tt, tw, tris.shape[0], tb, bw, nodes.shape[0], width, height, sobol_v, spheres, **kw)
+    ints = None
+    if nodes.shape[0] > FLOAT_EXACT_INTS:
+        # beyond what the reference's float-encoded node indices can express: hand the oracle the
+        # integers themselves (OrScene.bvhInts)
+        ints = np.stack([nodes["triangleNum"], nodes["offsetOrRc"], nodes["axis"]], axis=1)
+    return OracleScene(tt, tw, tris.shape[0], tb, bw, nodes.shape[0], width, height, sobol_v, spheres, bvh_ints=ints, **kw)

@@ -24,6 +24,11 @@ CASES = {
     "dragon1m": (0, 8, 1, 1920, 1080, 4, (520, 536)),
     "sponza": (1, 64, 1, 3840, 2160, 4, (700, 716)),
     "stress10m": (0, 8, 8, 1920, 1080, 8, (500, 516)),
+    # three copies: 3.9M triangles, 7.9M nodes -- the largest of this family that the reference's
+    # BVH texture can express: it stores node indices as floats and the shader recovers them with
+    # int(f + 0.5) (frag:180-182), which is exact only below 2^23.  The 10.5M-triangle scene is
+    # beyond that; the oracle then takes the same integers from an int array (oracle_lib).
+    "stress3m9": (0, 8, 3, 1920, 1080, 8, (560, 576)),
 }
 
 
@@ -44,7 +49,7 @@ def _rays_for(tris, seed, n=50000):
     return o, d
 
 
-@pytest.mark.parametrize("name", ["dragon1m", "sponza", "stress10m"])
+@pytest.mark.parametrize("name", ["dragon1m", "sponza", "stress10m", "stress3m9"])
 def test_benchmark_workload_at_full_size(name):
     kind, level, copies, W, H, bounces, band = CASES[name]
     sc = rt.Scene()
@@ -75,7 +80,9 @@ def test_benchmark_workload_at_full_size(name):
     assert np.array_equal(t, t_want)
     assert 0.3 < (id_want >= 0).mean()
 
-    # (i) + (iii): two frames through the default path
+    # (i) + (iii): two frames through the default path (the counters restart: the rays above
+    # included axis-parallel and far-away ones, which are re-traced by design)
+    r.reset()
     r.render(1, ro)
     img = r.read_mean()
     s = r.stats()
@@ -176,7 +183,7 @@ def test_two_contexts_with_different_sobol_tables():
     cam = rt.camera_default(W, H)
     ro = rt.rand_origins(77, 4)
     va = rt.sobol_default_table()
-    vb = (va * np.uint32(2654435761) + np.uint32(12345)).astype(np.uint32)     # any other table
+    vb = np.random.default_rng(5).integers(0, 1 << 32, size=va.shape[0], dtype=np.uint64).astype(np.uint32)   # any other table
     want = {}
     for key, v in (("a", va), ("b", vb)):
         want[key], _ = ol.scene_from_build(tris, nodes, W, H, v, sc.spheres()).render(cam, 1, ro)

@@ -7,6 +7,7 @@ import socket
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before raytracing_amd: the spawned ranks import this module first, see conftest.py)
 
 import raytracing_amd as rt
 from raytracing_amd import partition
@@ -79,5 +80,8 @@ def test_two_ranks_with_bound_sum_buffers_reduce_to_the_single_process_image(tmp
     ok = ~np.isnan(want_sum)
     assert np.allclose(got[ok], want_sum[ok], rtol=1e-5, atol=1e-4)
     mean = partition.mean_from_sum(got, total)
-    assert float(np.sqrt(np.mean((mean[ok].astype(np.float64) - want_mean[ok].astype(np.float64)) ** 2))) < 1e-6
+    one = partition.mean_from_sum(want_sum, total)
+    assert float(np.sqrt(np.mean((mean[ok].astype(np.float64) - one[ok].astype(np.float64)) ** 2))) < 1e-6
+    # and against the running mean the single process kept (frag:697 recurrence, other rounding)
+    assert float(np.sqrt(np.mean((mean[ok].astype(np.float64) - want_mean[ok].astype(np.float64)) ** 2))) < 1e-5
     assert np.nan_to_num(want_mean).max() > 0
