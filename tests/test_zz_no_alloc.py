@@ -13,8 +13,10 @@ pytestmark = pytest.mark.gpu
 
 def _device_call(r, torch, o, d):
     n = o.shape[0]
-    do = torch.from_numpy(o).cuda()
-    dd = torch.from_numpy(d).cuda()
+    do = torch.zeros((max(n, 1), 3), dtype=torch.float32, device="cuda")      # never an empty (null) allocation
+    dd = torch.zeros((max(n, 1), 3), dtype=torch.float32, device="cuda")
+    do[:n] = torch.from_numpy(o)
+    dd[:n] = torch.from_numpy(d)
     dt = torch.full((max(n, 1),), 7.0, dtype=torch.float32, device="cuda")
     di = torch.full((max(n, 1),), 7, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
