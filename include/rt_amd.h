@@ -143,6 +143,20 @@ typedef struct RtScene RtScene;     /* host-side scene assembly (Scene.h) */
 int rt_bvh_build(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity,
                  int64_t *node_count);
 
+/* The same builder with the split rule the reference's author left commented out at
+ * BVH.h:225-256 in place of the median (BVH.h:219-222): the range is sorted along each axis
+ * (std::sort; the permutation of libstdc++'s introsort is reproduced), prefix and suffix boxes
+ * are swept, and the split with the smallest Bound::getArea(left) + Bound::getArea(right) wins
+ * -- getArea as written at BVH.h:181-184, `dif.y + dif.z` included, and no triangle counts in
+ * the cost -- then the range is sorted along the winning axis, which becomes the node's `axis`.
+ * The node ORDER differs from rt_bvh_build's, so this is a separate mode, never a default.  The
+ * cost tends to split off one triangle at a time: trees get as deep as they are large, the build
+ * is quadratic, and rt_scene_upload refuses trees deeper than 60 levels (the shader's own stack
+ * holds 256 entries, frag:381).  n <= RT_SWEEP_MAX_TRIANGLES. */
+#define RT_SWEEP_MAX_TRIANGLES 16384
+int rt_bvh_build_sweep(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity,
+                       int64_t *node_count);
+
 /* Texture geometry of getTexture(), ObjectTexture.h:79-80 and 138-139: a count*per float
  * array stored in a (x*per) x y R32F texture. */
 int rt_texture_dims(int64_t count, int per, int *x, int *y);
@@ -310,6 +324,7 @@ int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d
  * rt_selftest_arith: the device's a/b, sqrt|a|, fma(a,b,a), and sin/cos of |b| (0 outside [0, 2*pi]), five
  * floats per element, to compare with the host's arithmetic. */
 int rt_selftest_nth_element(float *keys, int32_t *ids, int64_t n, int64_t nth);
+int rt_selftest_sort(float *keys, int32_t *ids, int64_t n);     /* the builder's sort against std::sort */
 int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out);
 
 const char *rt_last_error(const RtContext *ctx);    /* ctx may be NULL: last error of a call without a context */

@@ -6,6 +6,8 @@
  *   BVH.h:81-96    BVHNode, calDimension
  *   BVH.h:117-156  BVHTree::build
  *   BVH.h:188-264  BVHTree::split  (median split with std::nth_element, BVH.h:222)
+ *   BVH.h:157-185, 225-256  class Bound and the sweep split the author left commented out
+ *                  ("SAH"), offered as a second build mode
  *   BVH.h:267-287  buildLinerTree / addLinearNode
  *   ObjectTexture.h:69-182  getTexture(BVHTree&, ...)  (33 floats/triangle, 9 floats/node)
  *   Scene.h:54-65  pushModel's scale-then-translate
@@ -62,9 +64,28 @@ inline void tri_max(const OTriangle &t, float out[3]) {
     for (int k = 0; k < 3; k++) out[k] = std::max(std::max(t.v[0][k], t.v[1][k]), t.v[2][k]);
 }
 
+// class Bound, BVH.h:157-185.  getArea() is the reference's own formula, `dif.y + dif.z` where a
+// surface area would have dif.y * dif.z (BVH.h:181-184); the factor 2.0 is a double, applied to
+// the float sum and rounded back to float (exact).
+struct OBound {
+    float maxP[3], minP[3];
+    static OBound of(const OTriangle &t) { OBound b; tri_max(t, b.maxP); tri_min(t, b.minP); return b; }
+    OBound unite(const OBound &o) const {
+        OBound r;
+        for (int k = 0; k < 3; k++) { r.maxP[k] = std::max(maxP[k], o.maxP[k]); r.minP[k] = std::min(minP[k], o.minP[k]); }
+        return r;
+    }
+    float area() const {
+        const float dx = maxP[0] - minP[0], dy = maxP[1] - minP[1], dz = maxP[2] - minP[2];
+        const float s = dx * dy + dx * dz + dy + dz;
+        return (float)(2.0 * (double)s);
+    }
+};
+
 struct Builder {
     OTriangle *tris;
     int n;
+    bool sah = false;           // the block the author left commented out (BVH.h:225-256) instead of the median split
     int size = 0;
     std::vector<ONode *> pool;
     OLinearNode *linear = nullptr;
@@ -100,9 +121,36 @@ struct Builder {
         else now->dimension = 2;
 
         int mid = now->triangleNum / 2;
-        int dim = now->dimension;
-        std::nth_element(begin, begin + mid, end,
-                         [dim](const OTriangle &a, const OTriangle &b) { return a.center[dim] < b.center[dim]; });
+        if (!sah) {
+            int dim = now->dimension;
+            std::nth_element(begin, begin + mid, end,
+                             [dim](const OTriangle &a, const OTriangle &b) { return a.center[dim] < b.center[dim]; });
+        } else {
+            // BVH.h:225-256 ("SAH" in the author's comment) in place of BVH.h:219-222: sort along each
+            // axis, sweep prefix / suffix boxes, keep the split with the smallest areaLeft + areaRight
+            // (no triangle counts in the cost), first one found on ties; then sort along the winner.
+            int cnt = (int)(end - begin);
+            int axis = 0;
+            mid = 0;
+            float area = 10000000000.0f;
+            for (int i = 0; i < 3; i++) {
+                std::sort(begin, end, [i](const OTriangle &a, const OTriangle &b) { return a.center[i] < b.center[i]; });
+                std::vector<OBound> boundLeft(cnt), boundRight(cnt);
+                boundLeft[0] = OBound::of(*begin);
+                boundRight[cnt - 1] = OBound::of(*(end - 1));
+                for (int j = 1; j < cnt; j++) {
+                    boundLeft[j] = boundLeft[j - 1].unite(OBound::of(*(begin + j)));
+                    boundRight[cnt - 1 - j] = boundRight[cnt - 1 - j + 1].unite(OBound::of(*(end - 1 - j)));
+                }
+                for (int j = 0; j < cnt - 1; j++) {
+                    float area_t = boundLeft[j].area() + boundRight[j + 1].area();
+                    if (area_t < area) { area = area_t; axis = i; mid = j; }
+                }
+            }
+            std::sort(begin, end, [axis](const OTriangle &a, const OTriangle &b) { return a.center[axis] < b.center[axis]; });
+            mid++;
+            now->dimension = axis;
+        }
         now->lc = newNode(); size++;
         split(now->lc, begin, begin + mid);
         now->rc = newNode(); size++;
@@ -146,7 +194,25 @@ void bvh_oracle_push_model(float *positions, int nverts, const float scale[3], c
 // computed here, BVH.h:36-39); permuted in place.  nodes: room for 2n-1 records.
 // Returns the node count (BVHTree::size), or 0 for an empty scene (the reference would
 // dereference triangles[0]).
-int bvh_oracle_build(void *tris_v, int n, void *nodes_v) {
+static int build_common(void *tris_v, int n, void *nodes_v, bool sah);
+
+int bvh_oracle_build(void *tris_v, int n, void *nodes_v) { return build_common(tris_v, n, nodes_v, false); }
+
+// The same with the split rule of BVH.h:225-256 (see Builder::split).  std::sort is called as the
+// reference would call it, so the order among equal centres is libstdc++'s.  The cost has no
+// triangle counts, so trees can be very deep and the build quadratic: small scenes only.
+int bvh_oracle_build_sah(void *tris_v, int n, void *nodes_v) { return build_common(tris_v, n, nodes_v, true); }
+
+// std::sort alone on records of the reference's size (keys[i] plays center[dim]).
+void bvh_oracle_sort(float *keys, int *ids, int n) {
+    struct Rec { float key; int id; char pad[136]; };
+    std::vector<Rec> v(n);
+    for (int i = 0; i < n; i++) { v[i].key = keys[i]; v[i].id = ids[i]; }
+    std::sort(v.begin(), v.end(), [](const Rec &a, const Rec &b) { return a.key < b.key; });
+    for (int i = 0; i < n; i++) { keys[i] = v[i].key; ids[i] = v[i].id; }
+}
+
+static int build_common(void *tris_v, int n, void *nodes_v, bool sah) {
     OTriangle *tris = (OTriangle *)tris_v;
     if (n <= 0) return 0;
     for (int i = 0; i < n; i++) {
@@ -157,7 +223,7 @@ int bvh_oracle_build(void *tris_v, int n, void *nodes_v) {
             tris[i].center[k] = c / 2.0f;
         }
     }
-    Builder b; b.tris = tris; b.n = n;
+    Builder b; b.tris = tris; b.n = n; b.sah = sah;
     ONode *root = b.newNode();
     b.size = 1;
     b.split(root, tris, tris + n);

@@ -22,6 +22,7 @@ RT_MAX_SPHERES = 10
 RT_SOBOL_WORDS = 512
 RT_MAX_BOUNCES = 8
 RT_NOALLOC_MAX_RAYS = 262144
+RT_SWEEP_MAX_TRIANGLES = 16384
 PIPELINE_WAVEFRONT = 0
 PIPELINE_MEGAKERNEL = 1
 PIPELINE_PERSISTENT = 2
@@ -68,6 +69,8 @@ class RtOptions(C.Structure):
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
 _PROTOS = {
     "rt_bvh_build": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "rt_bvh_build_sweep": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "rt_selftest_sort": (_int, [_vp, _vp, _i64]),
     "rt_texture_dims": (_int, [_i64, _int, C.POINTER(_int), C.POINTER(_int)]),
     "rt_pack_triangle_texture": (_int, [_vp, _i64, _vp, _int, _int]),
     "rt_pack_bvh_texture": (_int, [_vp, _i64, _vp, _int, _int]),
@@ -200,13 +203,14 @@ def rand_origins(seed, count):
     return np.array([lib.rt_rand_origin(C.byref(state)) for _ in range(count)], dtype=np.float32)
 
 
-def bvh_build(tris):
-    """Returns (permuted triangles, nodes); `tris` is not modified."""
+def bvh_build(tris, sweep=False):
+    """Returns (permuted triangles, nodes); `tris` is not modified.  sweep: the split rule the
+    reference's author left commented out (rt_bvh_build_sweep) instead of the median."""
     tris = np.ascontiguousarray(tris, dtype=TRIANGLE_DTYPE).copy()
     n = tris.shape[0]
     nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
     cnt = C.c_int64(0)
-    _check(lib.rt_bvh_build(_ptr(tris), n, _ptr(nodes), nodes.shape[0], C.byref(cnt)))
+    _check((lib.rt_bvh_build_sweep if sweep else lib.rt_bvh_build)(_ptr(tris), n, _ptr(nodes), nodes.shape[0], C.byref(cnt)))
     return tris, nodes[:cnt.value]
 
 

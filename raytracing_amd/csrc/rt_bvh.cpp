@@ -163,11 +163,74 @@ void select_nth(Rec *first, Rec *nth, Rec *last, Less lt) {
     insertion_sort(first, last, lt);
 }
 
+// ---- libstdc++ std::sort (introsort + final insertion sort), restated on Rec* ----------
+
+void sort_heap(Rec *first, Rec *last, Less lt) {
+    while (last - first > 1) {
+        --last;
+        Rec value = *last;          // __pop_heap(first, last, last)
+        *last = *first;
+        adjust_heap(first, 0, last - first, value, lt);
+    }
+}
+
+void unguarded_linear_insert(Rec *last, Less lt) {
+    Rec val = *last;
+    Rec *next = last - 1;
+    while (lt(val, *next)) {
+        *last = *next;
+        last = next;
+        --next;
+    }
+    *last = val;
+}
+
+void introsort_loop(Rec *first, Rec *last, int64_t depth_limit, Less lt) {
+    while (last - first > 16) {
+        if (depth_limit == 0) {     // __partial_sort(first, last, last)
+            heap_select(first, last, last, lt);
+            sort_heap(first, last, lt);
+            return;
+        }
+        --depth_limit;
+        Rec *cut = partition_pivot(first, last, lt);
+        introsort_loop(cut, last, depth_limit, lt);
+        last = cut;
+    }
+}
+
+void sort_recs(Rec *first, Rec *last, Less lt) {
+    if (first == last) return;
+    introsort_loop(first, last, (int64_t)floor_log2(last - first) * 2, lt);
+    if (last - first > 16) {        // __final_insertion_sort
+        insertion_sort(first, first + 16, lt);
+        for (Rec *i = first + 16; i != last; ++i) unguarded_linear_insert(i, lt);
+    } else {
+        insertion_sort(first, last, lt);
+    }
+}
+
 // ---- the recursion of BVHTree::split ------------------------------------------------
+
+// class Bound of BVH.h:157-185 with its getArea() as written (`dif.y + dif.z`, not a product)
+struct SweepBox {
+    float mx[3], mn[3];
+    void set(const Rec &r) { for (int c = 0; c < 3; c++) { mx[c] = r.mx[c]; mn[c] = r.mn[c]; } }
+    void unite(const SweepBox &a, const Rec &r) {
+        for (int c = 0; c < 3; c++) { mx[c] = (a.mx[c] < r.mx[c]) ? r.mx[c] : a.mx[c]; mn[c] = (r.mn[c] < a.mn[c]) ? r.mn[c] : a.mn[c]; }
+    }
+    float area() const {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        const float s = dx * dy + dx * dz + dy + dz;
+        return (float)(2.0 * (double)s);
+    }
+};
 
 struct Build {
     Rec *recs;
     RtLinearBVHNode *nodes;
+    bool sweep = false;             // split rule of BVH.h:225-256 instead of the median
+    std::vector<SweepBox> left, right;
 
     void range(int64_t begin, int64_t end, int64_t k, int fork_levels) {
         RtLinearBVHNode &nd = nodes[k];
@@ -195,12 +258,37 @@ struct Build {
         if (dx > dy && dx > dz) dim = 0;
         else if (dy > dz) dim = 1;
         else dim = 2;
-        const int64_t mid = count / 2;      // BVH.h:219
-        select_nth(recs + begin, recs + begin + mid, recs + end, Less{dim});
+        int64_t mid = count / 2;            // BVH.h:219
+        if (!sweep) {
+            select_nth(recs + begin, recs + begin + mid, recs + end, Less{dim});
+        } else {
+            // BVH.h:225-256: sort along each axis, sweep prefix and suffix boxes, keep the split
+            // with the smallest areaLeft + areaRight (first one on ties), sort along its axis
+            int axis = 0;
+            mid = 0;
+            float area = 10000000000.0f;
+            Rec *first = recs + begin, *last = recs + end;
+            for (int i = 0; i < 3; i++) {
+                sort_recs(first, last, Less{i});
+                left[0].set(first[0]);
+                right[(size_t)count - 1].set(first[count - 1]);
+                for (int64_t j = 1; j < count; j++) {
+                    left[(size_t)j].unite(left[(size_t)j - 1], first[j]);
+                    right[(size_t)(count - 1 - j)].unite(right[(size_t)(count - j)], first[count - 1 - j]);
+                }
+                for (int64_t j = 0; j < count - 1; j++) {
+                    const float area_t = left[(size_t)j].area() + right[(size_t)j + 1].area();
+                    if (area_t < area) { area = area_t; axis = i; mid = j; }
+                }
+            }
+            sort_recs(first, last, Less{axis});
+            mid++;
+            dim = axis;
+        }
         nd.triangleNum = (int32_t)count;
         nd.offsetOrRc = (int32_t)(k + 2 * mid);
         nd.axis = dim;
-        if (fork_levels > 0 && count > 65536) {
+        if (fork_levels > 0 && count > 65536 && !sweep) {
             std::thread left([=] { range(begin, begin + mid, k + 1, fork_levels - 1); });
             range(begin + mid, end, k + 2 * mid, fork_levels - 1);
             left.join();
@@ -224,11 +312,26 @@ inline float max3(float a, float b, float c) {
 
 extern "C" {
 
-int rt_bvh_build(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity,
-                 int64_t *node_count) {
+static int build_tree(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity, int64_t *node_count, bool sweep);
+
+int rt_bvh_build(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity, int64_t *node_count) {
+    return build_tree(tris, n, nodes, node_capacity, node_count, false);
+}
+
+int rt_bvh_build_sweep(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity, int64_t *node_count) {
+    return build_tree(tris, n, nodes, node_capacity, node_count, true);
+}
+
+static int build_tree(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t node_capacity,
+                      int64_t *node_count, bool sweep) {
     if (!tris || !nodes || n <= 0) { rt::set_global_error("rt_bvh_build: empty scene or null pointer"); return RT_E_INVALID; }
     if (n > (int64_t)1 << 30) { rt::set_global_error("rt_bvh_build: more than 2^30 triangles"); return RT_E_INVALID; }
     if (node_capacity < 2 * n - 1) { rt::set_global_error("rt_bvh_build: node_capacity < 2n-1"); return RT_E_INVALID; }
+    if (sweep && n > RT_SWEEP_MAX_TRIANGLES) {
+        // its trees can be as deep as they are large (the cost ignores triangle counts) and every node sorts its range four times
+        rt::set_global_error("rt_bvh_build_sweep: more than RT_SWEEP_MAX_TRIANGLES (16384) triangles");
+        return RT_E_INVALID;
+    }
     std::vector<Rec> recs((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         Rec &r = recs[(size_t)i];
@@ -241,8 +344,10 @@ int rt_bvh_build(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64_t no
             r.c[c] = s / 2.0f;
         }
     }
-    Build b{recs.data(), nodes};
-    b.range(0, n, 0, 3);
+    Build b;
+    b.recs = recs.data(); b.nodes = nodes; b.sweep = sweep;
+    if (sweep) { b.left.resize((size_t)n); b.right.resize((size_t)n); }
+    b.range(0, n, 0, sweep ? 0 : 3);
     // permute the caller's triangles into tree order and store their centres
     std::vector<RtTriangle> tmp(tris, tris + n);
     for (int64_t i = 0; i < n; i++) {
@@ -261,6 +366,15 @@ int rt_selftest_nth_element(float *keys, int32_t *ids, int64_t n, int64_t nth) {
     std::vector<Rec> v((size_t)n);
     for (int64_t i = 0; i < n; i++) { v[(size_t)i] = Rec{}; v[(size_t)i].c[0] = keys[i]; v[(size_t)i].id = (uint32_t)ids[i]; }
     select_nth(v.data(), v.data() + nth, v.data() + n, Less{0});
+    for (int64_t i = 0; i < n; i++) { keys[i] = v[(size_t)i].c[0]; ids[i] = (int32_t)v[(size_t)i].id; }
+    return RT_OK;
+}
+
+int rt_selftest_sort(float *keys, int32_t *ids, int64_t n) {
+    if (!keys || !ids || n < 0) { rt::set_global_error("rt_selftest_sort: bad argument"); return RT_E_INVALID; }
+    std::vector<Rec> v((size_t)n);
+    for (int64_t i = 0; i < n; i++) { v[(size_t)i] = Rec{}; v[(size_t)i].c[0] = keys[i]; v[(size_t)i].id = (uint32_t)ids[i]; }
+    sort_recs(v.data(), v.data() + n, Less{0});
     for (int64_t i = 0; i < n; i++) { keys[i] = v[(size_t)i].c[0]; ids[i] = (int32_t)v[(size_t)i].id; }
     return RT_OK;
 }

@@ -46,14 +46,17 @@ __device__ __forceinline__ float triangle_test(const float4 q0, const float4 q1,
     const vec3 N = rtm::mk(q2.y, q2.z, q2.w);
     const float D = q3.x;
     const float nd = rtm::dot(N, d);
-    if (nd == 0.0f) return -1.0f;
+    // The shader returns early after each failed test (frag:264-275); evaluating everything and
+    // combining the five rejections gives the same value (what follows a rejection is unused
+    // there, and nothing here traps), without divergent branches and with the whole record
+    // fetched in one go.
     const float t = -(rtm::dot(N, o) + D) / nd;
-    if (t < 0.0f) return -1.0f;
     const vec3 pHit = rtm::along(o, t, d);
-    if (rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pHit, v0))) < 0.0f) return -1.0f;
-    if (rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pHit, v1))) < 0.0f) return -1.0f;
-    if (rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pHit, v2))) < 0.0f) return -1.0f;
-    return t - 0.00001f;
+    const float e0 = rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pHit, v0)));
+    const float e1 = rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pHit, v1)));
+    const float e2 = rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pHit, v2)));
+    const bool reject = (nd == 0.0f) | (t < 0.0f) | (e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f);
+    return reject ? -1.0f : t - 0.00001f;
 }
 
 // The traversal loop of hitBVH, frag:380-421, as a per-lane state machine.  It visits children

@@ -66,6 +66,10 @@ def load(fused=True):
     vp, i = C.c_void_p, C.c_int
     lib.bvh_oracle_build.restype = i
     lib.bvh_oracle_build.argtypes = [vp, i, vp]
+    lib.bvh_oracle_build_sah.restype = i
+    lib.bvh_oracle_build_sah.argtypes = [vp, i, vp]
+    lib.bvh_oracle_sort.restype = None
+    lib.bvh_oracle_sort.argtypes = [vp, vp, i]
     lib.bvh_oracle_tex_dims.restype = None
     lib.bvh_oracle_tex_dims.argtypes = [i, i, C.POINTER(i), C.POINTER(i)]
     lib.bvh_oracle_pack_triangles.restype = None
@@ -99,13 +103,14 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def bvh_build(tris, lib=None):
-    """Reference-order BVH of `tris` (TRIANGLE_DTYPE; not modified): (permuted tris, nodes)."""
+def bvh_build(tris, lib=None, sah=False):
+    """Reference-order BVH of `tris` (TRIANGLE_DTYPE; not modified): (permuted tris, nodes).
+    sah: the split rule the reference's author left commented out (BVH.h:225-256)."""
     lib = lib or load()
     t = np.ascontiguousarray(tris, dtype=TRIANGLE_DTYPE).copy()
     n = t.shape[0]
     nodes = np.zeros(max(2 * n - 1, 1), dtype=NODE_DTYPE)
-    cnt = lib.bvh_oracle_build(_ptr(t), n, _ptr(nodes))
+    cnt = (lib.bvh_oracle_build_sah if sah else lib.bvh_oracle_build)(_ptr(t), n, _ptr(nodes))
     return t, nodes[:cnt]
 
 

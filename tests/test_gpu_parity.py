@@ -582,6 +582,34 @@ def test_render_from_loaded_obj_files_with_reference_camera(golden_dir, tmp_path
     assert np.nan_to_num(want3).max() > 1.0
 
 
+def test_sweep_built_tree_renders_like_the_oracle_on_the_same_tree():
+    """The build mode the reference's author left commented out (BVH.h:225-256) gives another
+    node order; the shader semantics on that tree are the same, so every pipeline must match the
+    oracle fed with the same tree.  Deep trees of that mode are refused at upload."""
+    W, H = 120, 80
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles(), sweep=True)
+    m_tris, m_nodes = rt.bvh_build(sc.triangles())
+    assert nodes.tobytes() != m_nodes.tobytes()
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 3)
+    want, st = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro, want_stats=True)
+    res = _render_all_pipelines(tris, nodes, cam, ro, W, H, spheres=sc.spheres())
+    for name, (img, rays) in res.items():
+        assert _same_image(img, want), name
+        assert rays == st["rays"], name
+    # closest hits do not depend on the tree, so the image equals the median tree's wherever no
+    # two triangles tie (the demo scene has none in view)
+    want_m, _ = _oracle_for(m_tris, m_nodes, W, H, sc.spheres()).render(cam, 1, ro)
+    assert np.array_equal(want, want_m)
+    # 300 random triangles: the sweep peels them off one by one, the tree is ~300 levels deep
+    t2, n2 = rt.bvh_build(scenes.random_triangles(300, 3), sweep=True)
+    r = rt.Renderer(16, 16)
+    with pytest.raises(rt.RtError, match="deeper than 60"):
+        r.upload(t2, n2)
+    r.close()
+
+
 def test_error_paths():
     r = rt.Renderer(16, 16)
     ro = rt.rand_origins(1, 1)

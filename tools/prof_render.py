@@ -2,6 +2,7 @@
 """Small render driver for profiling runs (rocprofv3 ... -- python3 tools/prof_render.py ...):
 builds a benchmark scene, renders a few frames through the C ABI and prints Mrays/s.  No torch."""
 import argparse
+import hashlib
 import os
 import sys
 import time
@@ -24,6 +25,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2)
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--count", action="store_true")
+    ap.add_argument("--checksum", action="store_true", help="print a hash of the resulting mean image")
+    ap.add_argument("--per-call", type=int, default=0, help="frames per rt_render_frames call (default: all at once)")
     a = ap.parse_args()
     sc = rt.Scene()
     if a.demo:
@@ -38,14 +41,17 @@ def main():
     r.synchronize()
     r.reset()
     t0 = time.perf_counter()
-    r.render(a.warmup + 1, ro[a.warmup:])
+    step = a.per_call if a.per_call > 0 else a.frames
+    for k in range(0, a.frames, step):
+        r.render(a.warmup + 1 + k, ro[a.warmup + k:a.warmup + min(k + step, a.frames)])
     r.synchronize()
     dt = time.perf_counter() - t0
     st = r.stats()
     ms, n = r.kernel_time()
     print(f"frames {a.frames} rays {st['rays']} wall {dt * 1e3:.2f} ms -> {st['rays'] / dt / 1e6:.1f} Mrays/s; "
           f"dominant kernel {ms:.2f} ms over {n} launches; nodes/ray {st['node_tests'] / max(st['rays'], 1):.1f} "
-          f"tris/ray {st['tri_tests'] / max(st['rays'], 1):.2f} retraced {st['retraced']}")
+          f"tris/ray {st['tri_tests'] / max(st['rays'], 1):.2f} retraced {st['retraced']}"
+          + (f" checksum {hashlib.sha1(r.read_mean().tobytes()).hexdigest()[:12]}" if a.checksum else ""))
 
 
 if __name__ == "__main__":
