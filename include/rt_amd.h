@@ -120,6 +120,14 @@ typedef struct RtOptions {
                                (RT_Screen.h:61): after every frame the mean is clamped to [0,1] and
                                rounded to a multiple of 1/255 (NaN becomes 0).  The plain sum is
                                not affected. */
+    int32_t overlap;        /* persistent pipeline only.  1 (default): consecutive batches of frames (calls
+                               of rt_render_frames, or the 64-frame batches of one call) alternate between
+                               two internal streams, so that a batch starts while the last paths of the
+                               previous one are still running; accumulation stays in frame order, and the
+                               context's stream waits for each batch, so reads and the caller's later work
+                               on that stream see the result.  Work the CALLER enqueues on the context's
+                               stream before a render call is not waited for by the rendering (none of it
+                               is an input of the rendering).  0: everything runs on the context's stream. */
 } RtOptions;
 #define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
 #define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */

@@ -63,7 +63,7 @@ class RtSceneInfo(C.Structure):
 
 class RtOptions(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
-                ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32)]
+                ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32), ("overlap", C.c_int32)]
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
@@ -306,8 +306,8 @@ class Renderer:
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
     def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True,
-                    history8=False):
-        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8))
+                    history8=False, overlap=True):
+        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8), int(overlap))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 
     def upload(self, tris, nodes):

@@ -56,6 +56,7 @@ struct SceneD {
     float arootMin[3];
     float arootMax[3];
     float originLimit;      // rays starting farther than this from the origin skip the index
+    unsigned long long *timeline;   // experiment builds (RT_EXP_TIMELINE): per wave start, end, rays, iterations
 };
 
 struct FrameD {

@@ -610,6 +610,43 @@ def test_sweep_built_tree_renders_like_the_oracle_on_the_same_tree():
     r.close()
 
 
+def test_overlapped_calls_equal_serial_calls():
+    """RtOptions.overlap: consecutive calls alternate between two internal streams.  One frame per
+    call (the reference's call pattern, main.cpp:124-172), resets, restores and reads in between:
+    bit-equal to everything on the context's stream, and to the oracle."""
+    W, H = 200, 120
+    sc = rt.Scene()
+    sc.push_synthetic(1, 6, 1, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(31, 40)
+    want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro[:12])
+    out = {}
+    for overlap in (True, False):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        r.set_options(overlap=overlap)
+        for k in range(40):
+            r.render(k + 1, ro[k:k + 1])
+        a = (r.read_mean(), r.read_sum(), r.stats()["rays"])
+        r.reset()                                           # a reset between overlapped calls
+        for k in range(0, 12, 3):
+            r.render(k + 1, ro[k:k + 3])
+        b = (r.read_mean(), r.read_sum(), r.stats()["rays"], r.stats()["frames"])
+        r.restore(a[0], a[1], 40)                           # and a restore
+        r.render(41, ro[:5])
+        r.render(46, ro[5:6])
+        c = (r.read_mean(), r.read_sum())
+        out[overlap] = (a, b, c)
+        r.close()
+    for x, y in zip(out[True], out[False]):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v, equal_nan=True) if isinstance(u, np.ndarray) else u == v
+    assert _same_image(out[True][1][0], want) and out[True][1][3] == 12
+
+
 def test_error_paths():
     r = rt.Renderer(16, 16)
     ro = rt.rand_origins(1, 1)

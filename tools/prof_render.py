@@ -36,12 +36,12 @@ def main():
     r = rt.make_renderer(sc, a.width, a.height, 0, max_bounces=a.bounces, pipeline=a.pipeline,
                          cull=not a.no_cull, count_work=a.count)
     ro = rt.rand_origins(20221003, a.warmup + a.frames)
-    if a.warmup:
-        r.render(1, ro[:a.warmup])
+    step = a.per_call if a.per_call > 0 else a.frames
+    for k in range(0, a.warmup, step):      # same call pattern as the timed part (touches every launch slot)
+        r.render(1 + k, ro[k:min(k + step, a.warmup)])
     r.synchronize()
     r.reset()
     t0 = time.perf_counter()
-    step = a.per_call if a.per_call > 0 else a.frames
     for k in range(0, a.frames, step):
         r.render(a.warmup + 1 + k, ro[a.warmup + k:a.warmup + min(k + step, a.frames)])
     r.synchronize()
