@@ -72,7 +72,7 @@ def cpu_baseline(rt, tris, nodes, spheres, cam, W, H, bounces, ro, budget_s=15.0
                       "oracle/rt_oracle.c with OpenMP over rows; no hitMin culling, re-traces excluded from the count"}
 
 
-def call_granularity(r, ro, bounces, pipeline, args, frames=64):
+def call_granularity(r, ro, opts, frames=64):
     """The drop-in call pattern: the reference's main loop (main.cpp:124-172) renders ONE frame per
     iteration, i.e. rt_render_frames(ctx, LoopNum, 1, &randOrigin).  Times `frames` frames issued
     as calls of 1 and of 8 frames (no host synchronisation between calls) next to the batched
@@ -81,7 +81,7 @@ def call_granularity(r, ro, bounces, pipeline, args, frames=64):
     frames = min(frames, len(ro) // 8 * 8)
     if frames < 8:
         return out
-    r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False, accel=not args.no_accel)
+    r.set_options(count_work=False, **opts)
     for per_call in (1, 8):
         for timed in (False, True):                         # one untimed pass first
             r.reset()
@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
     ap.add_argument("--resolution", default=None, help="WxH override for sensitivity runs (the named workload's resolution is the default)")
+    ap.add_argument("--gpu-index", action="store_true",
+                    help="build the search index on the GPU at upload (milliseconds instead of seconds; more boxes per ray)")
+    ap.add_argument("--no-overlap", action="store_true", help="keep every launch on the context's stream (RtOptions.overlap = 0)")
     ap.add_argument("--total-spp", type=int, default=0,
                     help="strong scaling: this many frames in the whole job, split evenly over ranks and steps "
                          "(overrides --spp-per-step; must be divisible by gpus * steps)")
@@ -151,11 +154,16 @@ def main():
     pipeline = {"wavefront": rt.PIPELINE_WAVEFRONT, "megakernel": rt.PIPELINE_MEGAKERNEL,
                 "persistent": rt.PIPELINE_PERSISTENT}[args.pipeline]
 
+    opts = dict(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, accel=not args.no_accel,
+                overlap=not args.no_overlap, index_build=rt.INDEX_BUILD_GPU if args.gpu_index else rt.INDEX_BUILD_HOST)
     r = rt.Renderer(W, H, local_rank)
+    r.set_options(count_work=False, **opts)
+    t_up = time.time()
     r.upload(tris, nodes)
+    r.synchronize()
+    upload_s = time.time() - t_up
     r.set_spheres(sc.spheres())
     r.set_camera(cam)
-    r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=False, accel=not args.no_accel)
     sum_t = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     r.bind_sum_buffer(sum_t.data_ptr())
     info = r.scene_info()
@@ -217,7 +225,7 @@ def main():
         mean_img = (sum_t / float(K * world * F)).cpu().numpy()
         value = rays_total / elapsed / 1e6
         # instrumented re-run of this rank's timed frames: identical traversal, counts the work
-        r.set_options(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, count_work=True, accel=not args.no_accel)
+        r.set_options(count_work=True, **opts)
         r.reset()
         ksteps = min(K, 2)
         for s in range(ksteps):
@@ -264,6 +272,8 @@ def main():
                        "pipeline": args.pipeline, "cull": not args.no_cull, "search_index": not args.no_accel,
                        "parallelism": f"spp-partition x{world}, one RCCL sum-reduce" if world > 1 else "single GPU",
                        "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
+                       "scene_upload_s": round(upload_s, 3), "index_build": "gpu" if args.gpu_index else "host",
+                       "overlap": not args.no_overlap,
                        "image_mean": float(mean_img.mean())},
             # The scene (index + triangles) is served by L1 / L2 / Infinity Cache, so the roof that
             # binds is the fp32 vector unit, not HBM: `achieved` is the algorithmic fp32 work (21 flop
@@ -292,7 +302,7 @@ def main():
                          "l2_hit_rate": pmc.get("l2_hit_rate") if pmc else None},
         }
         if world == 1 and not args.no_call_granularity and pipeline == rt.PIPELINE_PERSISTENT:
-            result["call_granularity"] = call_granularity(r, ro, bounces, pipeline, args)
+            result["call_granularity"] = call_granularity(r, ro, opts)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(rt, tris, nodes, sc.spheres(), cam, W, H, bounces, ro)
         else:

@@ -26,6 +26,8 @@ RT_SWEEP_MAX_TRIANGLES = 16384
 PIPELINE_WAVEFRONT = 0
 PIPELINE_MEGAKERNEL = 1
 PIPELINE_PERSISTENT = 2
+INDEX_BUILD_HOST = 0
+INDEX_BUILD_GPU = 1
 
 # numpy views of the C structs of include/rt_amd.h
 TRIANGLE_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("n", "<f4", (3, 3)), ("tex", "<f4", (3, 2)),
@@ -63,7 +65,8 @@ class RtSceneInfo(C.Structure):
 
 class RtOptions(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
-                ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32), ("overlap", C.c_int32)]
+                ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32), ("overlap", C.c_int32),
+                ("index_build", C.c_int32)]
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
@@ -306,8 +309,8 @@ class Renderer:
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
     def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True,
-                    history8=False, overlap=True):
-        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8), int(overlap))
+                    history8=False, overlap=True, index_build=0):
+        o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8), int(overlap), int(index_build))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 
     def upload(self, tris, nodes):
@@ -410,6 +413,8 @@ def make_renderer(scene, width, height, device=0, camera=None, **options):
     """main.cpp:101-121 in one call: build the BVH of `scene`, upload it, set camera and spheres."""
     tris, nodes = bvh_build(scene.triangles())
     r = Renderer(width, height, device)
+    if options:
+        r.set_options(**options)        # index_build is read at upload
     r.upload(tris, nodes)
     r.set_spheres(scene.spheres())
     r.set_camera(camera if camera is not None else camera_default(width, height))

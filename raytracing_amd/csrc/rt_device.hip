@@ -3,16 +3,20 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
 #include "rt_accel.h"
+#include "rt_gpubuild.h"
 #include "rt_internal.h"
 #include "rt_kernels.h"
 #include "rt_shade.h"
@@ -789,6 +793,24 @@ int resolve_events(RtContext *ctx) {
     return RT_OK;
 }
 
+// fn(begin, end) over [0, n) on up to 16 host threads (the upload's per-record conversions).
+template <typename Fn>
+void parallel_for(int64_t n, Fn fn) {
+    const int64_t minChunk = 32768;
+    int threads = (int)std::min<int64_t>(std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u), (n + minChunk - 1) / minChunk);
+    if (threads <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        const int64_t b = t * per, e = std::min(n, b + per);
+        if (b >= e) break;
+        pool.emplace_back([=] { fn(b, e); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Converts the reference's linear tree + triangle list into the device layout; validates the
 // tree shape first so that a malformed tree is rejected on the host instead of faulting on the
 // GPU.
@@ -825,41 +847,49 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
     // (verify_reference_reaches), which stands for every box above it only when each leaf box
     // IS that min/max box and each parent box contains its children (BVH.h:190-197 builds them
     // so).  A tree with other boxes is still rendered, in the reference's order only.
-    boxesExact = true;
-    for (int64_t k = 0; k < m && boxesExact; k++) {
-        const RtLinearBVHNode &nd = nodes[k];
-        if (nd.triangleNum == 1) {
-            const RtTriangle &t = tris[nd.offsetOrRc];
-            for (int c = 0; c < 3; c++) {
-                const float lo = std::fmin(std::fmin(t.v[0][c], t.v[1][c]), t.v[2][c]);
-                const float hi = std::fmax(std::fmax(t.v[0][c], t.v[1][c]), t.v[2][c]);
-                if (!(nd.minBound[c] == lo) || !(nd.maxBound[c] == hi)) boxesExact = false;
+    std::atomic<bool> exact{true};
+    parallel_for(m, [&](int64_t kb, int64_t ke) {
+        bool ok = true;
+        for (int64_t k = kb; k < ke && ok; k++) {
+            const RtLinearBVHNode &nd = nodes[k];
+            if (nd.triangleNum == 1) {
+                const RtTriangle &t = tris[nd.offsetOrRc];
+                for (int c = 0; c < 3; c++) {
+                    const float lo = std::fmin(std::fmin(t.v[0][c], t.v[1][c]), t.v[2][c]);
+                    const float hi = std::fmax(std::fmax(t.v[0][c], t.v[1][c]), t.v[2][c]);
+                    if (!(nd.minBound[c] == lo) || !(nd.maxBound[c] == hi)) ok = false;
+                }
+            } else {
+                const RtLinearBVHNode *ch[2] = {&nodes[k + 1], &nodes[nd.offsetOrRc]};
+                for (int s = 0; s < 2; s++)
+                    for (int c = 0; c < 3; c++)
+                        if (!(nd.minBound[c] <= ch[s]->minBound[c]) || !(nd.maxBound[c] >= ch[s]->maxBound[c])) ok = false;
             }
-        } else {
-            const RtLinearBVHNode *ch[2] = {&nodes[k + 1], &nodes[nd.offsetOrRc]};
-            for (int s = 0; s < 2; s++)
-                for (int c = 0; c < 3; c++)
-                    if (!(nd.minBound[c] <= ch[s]->minBound[c]) || !(nd.maxBound[c] >= ch[s]->maxBound[c])) boxesExact = false;
         }
-    }
+        if (!ok) exact = false;
+    });
+    boxesExact = exact.load();
     if (maxDepth > 60) return fail(ctx, RT_E_INVALID, "scene upload: tree deeper than 60 levels");
     auto ref_of = [&](int64_t k) -> uint32_t {
         return nodes[k].triangleNum == 1 ? (LEAF_BIT | (uint32_t)nodes[k].offsetOrRc) : interiorIdx[(size_t)k];
     };
-    hNodes.assign((size_t)nInterior * 4, make_float4(0, 0, 0, 0));
-    for (int64_t k = 0; k < m; k++) {
-        const RtLinearBVHNode &nd = nodes[k];
-        if (nd.triangleNum == 1) continue;
-        const RtLinearBVHNode &L = nodes[k + 1], &R = nodes[nd.offsetOrRc];
-        float4 *o = &hNodes[(size_t)interiorIdx[(size_t)k] * 4];
-        o[0] = make_float4(L.minBound[0], L.minBound[1], L.minBound[2], L.maxBound[0]);
-        o[1] = make_float4(L.maxBound[1], L.maxBound[2], R.minBound[0], R.minBound[1]);
-        o[2] = make_float4(R.minBound[2], R.maxBound[0], R.maxBound[1], R.maxBound[2]);
-        uint32_t w[4] = {ref_of(k + 1), ref_of(nd.offsetOrRc), (uint32_t)nd.axis, 0u};
-        std::memcpy(&o[3], w, 16);
-    }
+    hNodes.resize((size_t)nInterior * 4);
+    parallel_for(m, [&](int64_t kb, int64_t ke) {
+        for (int64_t k = kb; k < ke; k++) {
+            const RtLinearBVHNode &nd = nodes[k];
+            if (nd.triangleNum == 1) continue;
+            const RtLinearBVHNode &L = nodes[k + 1], &R = nodes[nd.offsetOrRc];
+            float4 *o = &hNodes[(size_t)interiorIdx[(size_t)k] * 4];
+            o[0] = make_float4(L.minBound[0], L.minBound[1], L.minBound[2], L.maxBound[0]);
+            o[1] = make_float4(L.maxBound[1], L.maxBound[2], R.minBound[0], R.minBound[1]);
+            o[2] = make_float4(R.minBound[2], R.maxBound[0], R.maxBound[1], R.maxBound[2]);
+            uint32_t w[4] = {ref_of(k + 1), ref_of(nd.offsetOrRc), (uint32_t)nd.axis, 0u};
+            std::memcpy(&o[3], w, 16);
+        }
+    });
     hTris.resize((size_t)n * 4); hMats.resize((size_t)n * 5);
-    for (int64_t i = 0; i < n; i++) {
+    parallel_for(n, [&](int64_t ib, int64_t ie) {
+    for (int64_t i = ib; i < ie; i++) {
         const RtTriangle &t = tris[i];
         const vec3 v0 = rtm::mk(t.v[0][0], t.v[0][1], t.v[0][2]);
         const vec3 v1 = rtm::mk(t.v[1][0], t.v[1][1], t.v[1][2]);
@@ -881,6 +911,7 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
         hMats[(size_t)i * 5 + 3] = make_float4(tg.x, tg.y, tg.z, bt.x);
         hMats[(size_t)i * 5 + 4] = make_float4(bt.y, bt.z, 0.0f, 0.0f);
     }
+    });
     S = SceneD{};
     float maxAbs = 0.0f;
     for (int c = 0; c < 3; c++) {
@@ -935,6 +966,7 @@ int rt_default_options(RtOptions *out) {
     out->accel = 1;
     out->history8 = 0;
     out->overlap = 1;
+    out->index_build = RT_INDEX_BUILD_HOST;
     return RT_OK;
 }
 
@@ -1040,6 +1072,7 @@ int rt_set_options(RtContext *ctx, const RtOptions *opt) {
     if (!ctx || !opt) return fail(ctx, RT_E_INVALID, "rt_set_options: null pointer");
     if (opt->max_bounces < 1 || opt->max_bounces > RT_MAX_BOUNCES) return fail(ctx, RT_E_INVALID, "rt_set_options: max_bounces must be in 1..8");
     if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL && opt->pipeline != RT_PIPELINE_PERSISTENT) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
+    if (opt->index_build != RT_INDEX_BUILD_HOST && opt->index_build != RT_INDEX_BUILD_GPU) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown index_build");
     ctx->opt = *opt;
     ctx->frame.maxBounces = opt->max_bounces;
     return RT_OK;
@@ -1049,12 +1082,17 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     if (!ctx || !tris || !nodes) return fail(ctx, RT_E_INVALID, "rt_scene_upload: null pointer");
     std::vector<float4> hNodes, hTris, hMats; SceneD S;
     bool boxesExact = true;
+    const double tStart = now_ms();
     int rc = build_device_scene(ctx, tris, n, nodes, m, hNodes, hTris, hMats, S, boxesExact);
     if (rc != RT_OK) return rc;
-    // search index for the extend stage (skipped when RT_AMD_NO_ACCEL is set)
+    const double tConverted = now_ms();
+    // search index for the extend stage (skipped when RT_AMD_NO_ACCEL is set): built here on the
+    // host (binned SAH), or further down on the device (RtOptions.index_build)
     rt::Accel accel;
     bool haveAccel = false;
-    if (boxesExact && !getenv("RT_AMD_NO_ACCEL")) {
+    const bool wantIndex = boxesExact && !getenv("RT_AMD_NO_ACCEL");
+    const bool gpuBuild = wantIndex && ctx->opt.index_build == RT_INDEX_BUILD_GPU;
+    if (wantIndex && !gpuBuild) {
         const float maxAbs = S.cullEps * 1024.0f;
         if (rt::build_accel(tris, n, maxAbs, 1, accel) == RT_OK && accel.directLeaves && accel.wideStack <= 160) {
             haveAccel = true;
@@ -1077,16 +1115,38 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     HIP_TRY(ctx, hipMemcpy(ctx->dMats, hMats.data(), hMats.size() * sizeof(float4), hipMemcpyHostToDevice));
     S.nodes = ctx->dNodes; S.tris = ctx->dTris; S.mats = ctx->dMats;
     S.anodes = nullptr; S.arootRef = REF_NONE; S.aovf = nullptr; S.aovfStride = 0; S.aldsEntries = 1;
+    uint32_t indexNodes = 0; int indexStackNeed = 0;
     if (haveAccel) {
         const size_t ab = std::max<size_t>(accel.wide.size(), 1) * sizeof(rt::WideNode);
         HIP_TRY(ctx, hipMalloc(&ctx->dANodes, ab));
         if (!accel.wide.empty()) HIP_TRY(ctx, hipMemcpy(ctx->dANodes, accel.wide.data(), accel.wide.size() * sizeof(rt::WideNode), hipMemcpyHostToDevice));
-        S.anodes = ctx->dANodes;
         S.arootRef = accel.wide.empty() ? accel.rootRef : accel.wideRootRef;
         for (int c = 0; c < 3; c++) { S.arootMin[c] = accel.rootMin[c]; S.arootMax[c] = accel.rootMax[c]; }
+        indexNodes = (uint32_t)accel.wide.size();
+        indexStackNeed = std::max(accel.wideStack, 1);
+    } else if (gpuBuild) {
+        rt::GpuIndex gi; std::string gerr;
+        const int grc = rt::build_index_gpu(ctx->dTris, n, S.rootMin, S.rootMax, S.cullEps * 1024.0f, ctx->stream, gi, gerr);
+        if (grc != RT_OK) return fail(ctx, grc, "rt_scene_upload: " + gerr);
+        if (3 * gi.wideDepth + 1 <= 160) {
+            haveAccel = true;
+            ctx->dANodes = (float4 *)gi.wide;
+            if (!ctx->dANodes) HIP_TRY(ctx, hipMalloc(&ctx->dANodes, sizeof(rt::WideNode)));    // one-triangle scene: never read
+            S.arootRef = gi.rootRef;
+            for (int c = 0; c < 3; c++) { S.arootMin[c] = gi.rootMin[c]; S.arootMax[c] = gi.rootMax[c]; }
+            indexNodes = gi.wideCount;
+            indexStackNeed = std::max(3 * gi.wideDepth + 1, 1);
+            if (getenv("RT_AMD_VERBOSE"))
+                fprintf(stderr, "rt_amd: search index built on the GPU: %u 4-wide nodes, %d levels\n", gi.wideCount, gi.wideDepth);
+        } else {
+            hipFree(gi.wide);       // deeper than the traversal stack allows: render in the reference's order
+        }
+    }
+    if (haveAccel) {
+        S.anodes = ctx->dANodes;
         S.originLimit = 4.0f * (S.cullEps * 1024.0f);
         // deferred-node slots: the first ones in LDS, the rest (rarely reached) in global memory
-        const int need = std::max(accel.wideStack, 1);
+        const int need = indexStackNeed;
         S.aldsEntries = std::min(need, ctx->accelLdsEntries);
         S.aovfStride = (uint32_t)ctx->numCU * 8u * BLOCK;
         // overflow column per thread: the deeper deferred nodes, or the whole stack of an exact re-trace
@@ -1104,8 +1164,11 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
 #endif
     ctx->scene = S; ctx->nTris = n; ctx->nInterior = n - 1; ctx->haveScene = true;
     ctx->boxesExact = boxesExact;
-    ctx->nIndexNodes = haveAccel ? (int64_t)accel.wide.size() : 0;
-    ctx->indexStackNeed = haveAccel ? std::max(accel.wideStack, 1) : 0;
+    if (getenv("RT_AMD_VERBOSE"))
+        fprintf(stderr, "rt_amd: upload of %lld triangles: host conversion %.1f ms, index + copies %.1f ms\n", (long long)n,
+                tConverted - tStart, now_ms() - tConverted);
+    ctx->nIndexNodes = haveAccel ? (int64_t)indexNodes : 0;
+    ctx->indexStackNeed = haveAccel ? indexStackNeed : 0;
     return RT_OK;
 }
 

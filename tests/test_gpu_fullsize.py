@@ -110,6 +110,59 @@ def test_benchmark_workload_at_full_size(name):
     r.close()
 
 
+@pytest.mark.parametrize("case", ["one", "two", "three", "duplicates", "random", "dragon1m"])
+def test_index_built_on_the_gpu(case):
+    """RtOptions.index_build = GPU: the search index is a Morton-order tree built on the device.
+    Whatever the index, the proof step keeps the reference's answers: rays and images must equal
+    the oracle's (and the host-built index's), including scenes of one to three triangles and
+    triangles with identical Morton codes."""
+    W, H = 96, 64
+    if case == "dragon1m":
+        sc = rt.Scene()
+        sc.push_synthetic(0, 8, 1, 12345)
+        t0 = sc.triangles()
+    elif case == "duplicates":
+        t0 = scenes.random_triangles(200, 9, snap=0.5)
+        t0 = np.concatenate([t0, t0[:50], t0[:50]])         # coincident triangles: equal keys, exact ties
+    else:
+        t0 = scenes.random_triangles({"one": 1, "two": 2, "three": 3, "random": 5000}[case], 17, extent=3.0, size=1.5)
+    tris, nodes = rt.bvh_build(t0)
+    osc = ol.scene_from_build(tris, nodes, W, H, rt.sobol_default_table(), None)
+    r = rt.Renderer(W, H)
+    r.set_options(index_build=rt.INDEX_BUILD_GPU)
+    r.upload(tris, nodes)
+    info = r.scene_info()
+    assert info["index_enabled"] == 1
+    if case == "dragon1m":
+        assert info["index_nodes"] > 300000
+    o, d = (_rays_for(tris, 3, n=30000) if case == "dragon1m" else scenes.random_rays(20000, 5, extent=4.0))
+    t_want, id_want = osc.hit_bvh(o, d)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, id_want) and np.array_equal(t, t_want)
+    cam = rt.camera_default(W, H) if case == "dragon1m" else rt.camera_from_angles((0.0, 0.0, 8.0), -90.0, 0.0, 30.0, W, H)
+    ro = rt.rand_origins(3, 2)
+    want, st = osc.render(cam, 1, ro, want_stats=True)
+    r.set_camera(cam)
+    for pipeline in (rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT):
+        r.set_options(pipeline=pipeline, index_build=rt.INDEX_BUILD_GPU)
+        r.reset()
+        r.render(1, ro)
+        got = r.read_mean()
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        m = ~np.isnan(want)
+        assert np.array_equal(got[m], want[m])
+        s = r.stats()
+        assert s["rays"] == st["rays"]
+        if case in ("random", "dragon1m"):
+            assert s["retraced"] <= 1e-3 * s["rays"] + 5
+    # uploading again with the host build replaces the index
+    r.set_options(index_build=rt.INDEX_BUILD_HOST)
+    r.upload(tris, nodes)
+    t, ids = r.trace_rays(o, d)
+    assert np.array_equal(ids, id_want) and np.array_equal(t, t_want)
+    r.close()
+
+
 def test_index_stack_overflow_and_small_lds_stack(monkeypatch):
     """The deferred-node stack of the index search keeps its first entries in LDS and the rest in
     a global column.  With only two LDS entries every deep traversal overflows; results must not

@@ -8,5 +8,5 @@ mkdir -p "$ROOT/expl"
 C=$ROOT/raytracing_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize \
   -Wno-unused-function -Wno-unused-value -Wno-unused-result "$@" \
-  -o "$ROOT/expl/librt_$NAME.so" $C/rt_device.hip $C/rt_bvh.cpp $C/rt_host.cpp $C/rt_scene.cpp $C/rt_accel.cpp -lpthread
+  -o "$ROOT/expl/librt_$NAME.so" $C/rt_device.hip $C/rt_gpubuild.hip $C/rt_bvh.cpp $C/rt_host.cpp $C/rt_scene.cpp $C/rt_accel.cpp -lpthread
 echo "built expl/librt_$NAME.so"
