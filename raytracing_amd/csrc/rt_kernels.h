@@ -53,6 +53,8 @@ struct SceneD {
     int32_t aldsEntries;    // deferred-node slots per lane kept in LDS; deeper ones go to aovf
     uint32_t *aovf;         // overflow slots, [slot][thread of the grid]
     uint32_t aovfStride;
+    uint32_t aovfRetrace;   // first overflow slot of the exact re-trace's stack: above every slot a deferred node can take,
+                            // because a lane may re-trace a pooled ray while its own ray has nodes deferred there
     float arootMin[3];
     float arootMax[3];
     float originLimit;      // rays starting farther than this from the origin skip the index

@@ -17,7 +17,7 @@ ro = rt.rand_origins(20221003, 8 + frames)
 r.render(1, ro[:8]); r.synchronize(); r.reset()
 r.render(9, ro[8:]); r.synchronize()
 ms, n = r.kernel_time()
-waves = 256 * 7 * 4
+waves = 256 * int(os.environ.get("WAVES_PER_SIMD", "7")) * 4
 buf = np.zeros((waves, 5), dtype=np.uint64)
 rt.lib.rt_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 assert rt.lib.rt_debug_timeline(r._h, buf.ctypes.data_as(C.c_void_p), waves) == 0
@@ -30,6 +30,9 @@ print(f"work ran out: min {(ex[ex > 0].min() - base) * tick:.0f}, median {np.med
 print(f"wave end    : min {(t1.min() - base) * tick:.0f}, median {np.median(t1 - base) * tick:.0f}, p90 {np.percentile(t1 - base, 90) * tick:.0f}, p99 {np.percentile(t1 - base, 99) * tick:.0f}, max {(t1.max() - base) * tick:.0f} us")
 dur = (t1 - t0) * tick
 print(f"wave life   : median {np.median(dur):.0f}, max {dur.max():.0f} us; iterations median {np.median(buf[:, 3]):.0f}, max {buf[:, 3].max()}; rays per wave median {np.median(buf[:, 2]):.0f}, max {buf[:, 2].max()}")
+shades = (buf[:, 3] >> np.uint64(32)).astype(np.float64)
+buf[:, 3] &= np.uint64(0xFFFFFFFF)
+print(f"shade passes per wave: median {np.median(shades):.0f}, max {shades.max():.0f}; rays per pass {buf[:, 2].sum() / max(shades.sum(), 1):.1f}")
 print(f"iteration time: median {np.median(dur / np.maximum(buf[:, 3], 1)):.2f} us")
 hist, edges = np.histogram((t1 - base) * tick, bins=20)
 for h, e in zip(hist, edges):
