@@ -593,258 +593,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
 #endif
 }
 
-// The same work with more paths than lanes.  Every wave owns a pool of 64 ray records in LDS
-// besides the 64 rays its lanes traverse.  A record is either READY (a ray that waits for a lane:
-// origin, direction, 1/direction, throughput, seed, pixel word) or FINISHED (a ray whose closest
-// hit is known and that waits for shading: origin, direction, hit distance, triangle, throughput,
-// seed, pixel word).  READY records are a stack at the bottom of the pool, FINISHED ones a stack
-// at its top.  A lane whose ray is finished deposits it and pops a READY one in the same step
-// (a dozen vector instructions and 28 LDS accesses, no arithmetic); when no READY record is
-// left the pool holds 64 FINISHED ones and the whole wave shades them at once -- proof,
-// material, scatter, Russian roulette, next ray or new camera ray -- every lane active.  In
-// k_paths the lanes shade their own rays, which runs the longest block of the kernel with half
-// of the lanes masked off and leaves finished lanes idle until enough of them have gathered.
-constexpr int POOL_WORDS = 14;                              // words per record
-constexpr int POOL_WAVE_WORDS = POOL_WORDS * 64;            // one wave's pool, laid out [word][record]
-constexpr uint32_t PIX_BOUNCE_SHIFT = 29;                   // pixel word: bounce in the top three bits
-constexpr float POOL_EXACT_FLAG = -1.0f;                    // sign of the stored hit distance: trace again in the reference's order
-
-template <bool COUNT, int OCC>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths_pool(const SceneD S, const FrameD F, const BatchD B,
-                                                 const float *__restrict__ sob, uint32_t *__restrict__ workHead, float *__restrict__ cur,
-                                                 WorkCounters *__restrict__ wc) {
-    extern __shared__ uint32_t lds_dyn[];
-    uint32_t *stack = lds_dyn + threadIdx.x;
-    uint32_t *pool = lds_dyn + (size_t)(S.aldsEntries + FAST_QUEUE_ENTRIES) * BLOCK + (threadIdx.x >> 6) * POOL_WAVE_WORDS;
-    uint32_t *ovf = S.aovf + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const uint32_t tilesX = (uint32_t)(F.width + 7) >> 3, tilesY = (uint32_t)(F.height + 7) >> 3;
-    const uint32_t framePix = tilesX * tilesY * 64u;
-    const uint32_t total = framePix * (uint32_t)B.nframes;
-    const size_t frameFloats = (size_t)F.width * (size_t)F.height * 3;
-    const uint32_t nWaves = gridDim.x * (BLOCK / 64);
-    const uint32_t maskX = (1u << B.bitsX) - 1u, maskY = (1u << B.bitsY) - 1u;
-    const int shiftSlot = B.bitsX + B.bitsY;
-    const uint32_t pixMask = (1u << PIX_BOUNCE_SHIFT) - 1u;
-
-    uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
-    FastTrav<COUNT> tv;
-    tv.cur = REF_NONE; tv.npend = 0; tv.sp = 0; tv.tie = false; tv.best = REF_NONE;
-    tv.hitMin = HIT_MIN_INIT; tv.hitCull = 0.0f;
-    tv.o = tv.d = tv.inv = rtm::mk(0.0f, 0.0f, 0.0f);
-    bool have = false;
-    uint32_t pix = 0;                                   // px | py << bitsX | frame slot << (bitsX + bitsY) | bounce << 29
-    vec3 thr = rtm::mk(0.0f, 0.0f, 0.0f);
-    uint32_t seed = 0;
-    uint32_t nReady = 0, nFinished = 0;                 // wave-uniform: records on the two stacks of the pool
-    uint32_t cNext = 0, cEnd = 0;                       // wave-uniform: the wave's current chunk of items
-    uint32_t chunk = (total / (4u * nWaves)) & ~63u;
-    chunk = chunk < 64u ? 64u : (chunk > 256u ? 256u : chunk);
-    bool exhausted = false;
-    const unsigned long long tStart = wall_clock64();
-    uint32_t iter = 0;
-#ifdef RT_EXP_TIMELINE
-    unsigned long long tlExhausted = 0, tlShades = 0;
-#endif
-    while (true) {
-        // a wave that runs for more than 30 s is broken: leave (the host reports it) instead of hanging the GPU
-        if (((++iter) & 0xFFFu) == 0u && wall_clock64() - tStart > 3000000000ull) {
-            if (lane == 0) atomicAdd(&wc->retraced, 1ull << 60);
-            break;
-        }
-#ifdef RT_EXP_TIMELINE
-        if (!(!exhausted || cNext < cEnd) && tlExhausted == 0) tlExhausted = wall_clock64();
-#endif
-        const bool fin = have && tv.finished();
-        const unsigned long long finMask = __ballot(fin), idleMask = __ballot(!have);
-        // ---- finished rays into the pool, READY rays out of it
-        if ((finMask | idleMask) != 0ull && (nReady > 0u || (finMask != 0ull && nFinished < 64u))) {
-            const uint32_t nF = (uint32_t)__popcll(finMask);
-            const uint32_t rankF = (uint32_t)__popcll(finMask & below);
-            const uint32_t rankPop = fin ? rankF : nF + (uint32_t)__popcll(idleMask & below);       // finished lanes are served first
-            const uint32_t wanting = (uint32_t)__popcll(finMask | idleMask);
-            const uint32_t pops = wanting < nReady ? wanting : nReady;
-            const uint32_t room = 64u - nFinished - (nReady - pops);
-            const bool deposit = fin && rankF < room;
-            const bool pop = (fin || !have) && rankPop < nReady;     // a finished lane that pops has rankF < pops <= room: it deposits too
-            // When the pool is full the two stacks touch and a lane's READY record sits in the very
-            // slot its FINISHED one goes to: read first, then write.
-            uint32_t rec[POOL_WORDS];
-            if (pop) {
-                const uint32_t *r = pool + (nReady - 1u - rankPop);
-#pragma unroll
-                for (int w = 0; w < POOL_WORDS; w++) rec[w] = r[w * 64];
-            }
-            if (deposit) {
-                uint32_t *r = pool + (63u - nFinished - rankF);
-                r[0 * 64] = __float_as_uint(tv.o.x); r[1 * 64] = __float_as_uint(tv.o.y); r[2 * 64] = __float_as_uint(tv.o.z);
-                r[3 * 64] = __float_as_uint(tv.d.x); r[4 * 64] = __float_as_uint(tv.d.y); r[5 * 64] = __float_as_uint(tv.d.z);
-                const bool exact = tv.tie || !tv.usable(S);
-                r[6 * 64] = __float_as_uint(exact ? -tv.hitMin : tv.hitMin);
-                r[7 * 64] = tv.best;
-                r[8 * 64] = __float_as_uint(thr.x); r[9 * 64] = __float_as_uint(thr.y); r[10 * 64] = __float_as_uint(thr.z);
-                r[11 * 64] = seed; r[12 * 64] = pix;
-                have = false;
-            }
-            if (pop) {
-                tv.o = rtm::mk(__uint_as_float(rec[0]), __uint_as_float(rec[1]), __uint_as_float(rec[2]));
-                tv.d = rtm::mk(__uint_as_float(rec[3]), __uint_as_float(rec[4]), __uint_as_float(rec[5]));
-                tv.inv = rtm::mk(__uint_as_float(rec[6]), __uint_as_float(rec[7]), __uint_as_float(rec[8]));
-                thr = rtm::mk(__uint_as_float(rec[9]), __uint_as_float(rec[10]), __uint_as_float(rec[11]));
-                seed = rec[12]; pix = rec[13];
-                // FastTrav::begin without the test of the root box (its children's boxes are tested in the first step)
-                tv.hitMin = HIT_MIN_INIT;
-                tv.hitCull = rtm::madd(HIT_MIN_INIT, 1.0001f, 1.0e-4f);
-                tv.best = REF_NONE; tv.tie = false; tv.sp = 0; tv.npend = 0;
-                tv.cur = REF_NONE;
-                if (COUNT) cNode++;
-                if (tv.usable(S)) {
-                    if (S.arootRef & LEAF_BIT) tv.queue_triangle(stack, BLOCK, S.arootRef & ~LEAF_BIT);    // one-triangle scene
-                    else tv.cur = S.arootRef;
-                }
-                have = true;
-            }
-            const uint32_t deposits = nF < room ? nF : room;
-            nFinished += deposits;
-            nReady -= pops;
-        }
-        // ---- shade the pool
-        const bool more = !exhausted || cNext < cEnd;
-        const bool finNow = have && tv.finished();          // (a ray the index cannot search is finished as soon as it is popped)
-        const unsigned long long busyMask = __ballot(have && !finNow), heldMask = __ballot(finNow);
-        bool shade = false;
-        if (nReady == 0u) {
-            if (more) shade = true;     // FINISHED records are shaded, the other lanes start new paths: a full wave either way
-            else shade = nFinished > 0u && (nFinished >= 32u || busyMask == 0ull);
-        }
-        if (shade) {
-#ifdef RT_EXP_TIMELINE
-            tlShades++;
-#endif
-            const bool isFin = lane < nFinished;
-            vec3 ro = rtm::mk(0.0f, 0.0f, 0.0f), rd = ro, rthr = ro;
-            float rt = HIT_MIN_INIT; uint32_t rbest = REF_NONE, rseed = 0u, rpix = 0u;
-            bool exact = false;
-            if (isFin) {
-                const uint32_t *r = pool + (64u - nFinished + lane);
-                ro = rtm::mk(__uint_as_float(r[0 * 64]), __uint_as_float(r[1 * 64]), __uint_as_float(r[2 * 64]));
-                rd = rtm::mk(__uint_as_float(r[3 * 64]), __uint_as_float(r[4 * 64]), __uint_as_float(r[5 * 64]));
-                rt = __uint_as_float(r[6 * 64]); rbest = r[7 * 64];
-                rthr = rtm::mk(__uint_as_float(r[8 * 64]), __uint_as_float(r[9 * 64]), __uint_as_float(r[10 * 64]));
-                rseed = r[11 * 64]; rpix = r[12 * 64];
-                exact = rt < 0.0f;
-                rt = fabsf(rt);
-                if (!exact && rbest != REF_NONE) {
-                    const vec3 rinv = rtm::mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    exact = !verify_reference_reaches(S, ro, rinv, rbest);
-                }
-            }
-            if (__ballot(exact) != 0ull) {
-                // rare: those rays are traced again in the reference's order, the lane's global column is the stack
-                if (exact) {
-                    float t; uint32_t tri;
-                    closest_triangle<true, COUNT>(S, ro, rd, ovf + (size_t)S.aovfRetrace * S.aovfStride, (int)S.aovfStride, t, tri, cNode, cTri);
-                    rt = t; rbest = tri;
-                    atomicAdd(&wc->retraced, 1ull);
-                }
-            }
-            bool out = false;                               // this lane has a READY record to write
-            vec3 no = ro, nd = rd, nthr = rthr;
-            uint32_t nseed = rseed, npix = rpix;
-            if (isFin) {
-                cRays++;
-                if (COUNT && rbest != REF_NONE) cHit++;
-                const uint32_t p = rpix & pixMask;
-                const uint32_t px = p & maskX, py = (p >> B.bitsX) & maskY, slot = p >> shiftSlot;
-                const int bounce = (int)(rpix >> PIX_BOUNCE_SHIFT);
-                const float uvx = ((float)px + 0.5f) / (float)F.width;
-                const float uvy = ((float)py + 0.5f) / (float)F.height;
-                const int si = ((int)slot * F.maxBounces + bounce) * 2;
-                Path pth;
-                pth.o = ro; pth.d = rd; pth.thr = rthr; pth.seed = rseed;
-                vec3 sample;
-                if (shade_hit(F, S, pth, rt, rbest, bounce, sob[si], sob[si + 1], uvx, uvy, sample)) {
-                    no = pth.o; nd = pth.d; nthr = pth.thr; nseed = pth.seed;
-                    npix = p | ((uint32_t)(bounce + 1) << PIX_BOUNCE_SHIFT);
-                    out = true;
-                } else {
-                    float *dst = cur + (size_t)slot * frameFloats + ((size_t)py * (size_t)F.width + px) * 3;
-                    dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
-                }
-            }
-            // new paths for the lanes without a continuing ray (a second round when the wave's chunk ran out half way)
-            uint32_t item = 0xFFFFFFFFu;
-            for (int round = 0; round < 2; round++) {
-                const unsigned long long freeMask = __ballot(!out && item == 0xFFFFFFFFu);
-                if (freeMask == 0ull || (exhausted && cNext >= cEnd)) break;
-                if (cNext >= cEnd) {
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)freeMask) - 1;
-                    if ((int)lane == leader) base = atomicAdd(workHead, chunk);
-                    base = __shfl(base, leader);
-                    if (base >= total) { exhausted = true; break; }
-                    cNext = base;
-                    cEnd = (total - base < chunk) ? total : base + chunk;
-                    const uint32_t share = ((total - cEnd) / (2u * nWaves)) & ~63u;
-                    chunk = share < 64u ? 64u : (share > 256u ? 256u : share);
-                }
-                const uint32_t nFree = (uint32_t)__popcll(freeMask);
-                const uint32_t left = cEnd - cNext;
-                const uint32_t give = nFree < left ? nFree : left;
-                const uint32_t rank = (uint32_t)__popcll(freeMask & below);
-                if (!out && item == 0xFFFFFFFFu && rank < give) item = cNext + rank;
-                cNext += give;
-                if (give == nFree) break;
-            }
-            if (item != 0xFFFFFFFFu) {
-                const uint32_t slot = item / framePix, rem = item - slot * framePix;
-                uint32_t px, py;
-                if (tile_pixel((int)(rem >> 6), (int)(rem & 63u), F.width, F.height, px, py)) {
-                    Path pth; float uvx, uvy;
-                    generate_path(F, B.randOrigin[slot], px, py, pth, uvx, uvy);
-                    no = pth.o; nd = pth.d; nthr = pth.thr; nseed = pth.seed;
-                    npix = px | (py << B.bitsX) | (slot << shiftSlot);
-                    out = true;
-                }
-            }
-            // READY records, packed at the bottom of the pool (every lane has read its FINISHED record by now)
-            const unsigned long long outMask = __ballot(out);
-            if (out) {
-                uint32_t *r = pool + (uint32_t)__popcll(outMask & below);
-                r[0 * 64] = __float_as_uint(no.x); r[1 * 64] = __float_as_uint(no.y); r[2 * 64] = __float_as_uint(no.z);
-                r[3 * 64] = __float_as_uint(nd.x); r[4 * 64] = __float_as_uint(nd.y); r[5 * 64] = __float_as_uint(nd.z);
-                r[6 * 64] = __float_as_uint(1.0f / nd.x); r[7 * 64] = __float_as_uint(1.0f / nd.y); r[8 * 64] = __float_as_uint(1.0f / nd.z);
-                r[9 * 64] = __float_as_uint(nthr.x); r[10 * 64] = __float_as_uint(nthr.y); r[11 * 64] = __float_as_uint(nthr.z);
-                r[12 * 64] = nseed; r[13 * 64] = npix;
-            }
-            nReady = (uint32_t)__popcll(outMask);
-            nFinished = 0u;
-            continue;                                       // lanes without a ray pop the new records at the top of the loop
-        }
-        if (busyMask == 0ull && heldMask == 0ull && nReady == 0u && nFinished == 0u && !more) break;
-        // ---- advance the rays by one step
-        const bool step = have && tv.can_step();
-        if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
-        const unsigned long long waiting = __ballot(have && tv.wants_test());
-        const unsigned long long stepping = __ballot(have && tv.can_step());
-        if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
-            if (have && tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
-        }
-    }
-#ifdef RT_EXP_TIMELINE
-    if (S.timeline) {
-        uint32_t r = cRays;
-        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-        if (lane == 0) {
-            unsigned long long *o = S.timeline + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 5;
-            o[0] = tStart; o[1] = wall_clock64(); o[2] = r; o[3] = iter | (tlShades << 32); o[4] = tlExhausted;
-        }
-    }
-#endif
-    flush_counters(wc, cRays, cNode, cTri, cHit);
-}
-
 // frag:697 (fp32 history) and the plain sum for the `nframes` samples of a batch, in frame order.
 __global__ __launch_bounds__(BLOCK) void k_accumulate_batch(const float *__restrict__ cur, float *__restrict__ sum,
                                                             float *__restrict__ mean, const size_t nfloats,
@@ -977,9 +725,6 @@ struct RtContext {
     bool inputDirty = false;        // work enqueued on `stream` (reset, restore) that the slots' streams must wait for
     hipEvent_t inputEvent = nullptr;
     int pathsOcc = 0;           // waves per SIMD the path kernel is compiled for (5, 6 or 7); 0 = by scene size
-    int pool = 0;               // 1: the pooled path kernel (k_paths_pool)
-    int poolOcc = 5;            // its waves per SIMD (4, 5 or 6)
-    int poolLdsEntries = 8;     // its deferred-node slots per lane in LDS
     int pathsLeafBatch = 8;     // lanes waiting for a triangle pass that trigger one in the path kernel
     WorkCounters *dCounters = nullptr;
     uint64_t frames = 0;
@@ -1270,9 +1015,6 @@ int rt_create(RtContext **out, int width, int height, int device) {
         if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
     }
     if (const char *env = getenv("RT_AMD_PATHS_OCC")) ctx->pathsOcc = atoi(env);
-    if (const char *env = getenv("RT_AMD_POOL")) ctx->pool = atoi(env) != 0;
-    if (const char *env = getenv("RT_AMD_POOL_OCC")) { const int v = atoi(env); if (v >= 4 && v <= 6) ctx->poolOcc = v; }
-    if (const char *env = getenv("RT_AMD_POOL_LDS_ENTRIES")) { const int v = atoi(env); if (v >= 1 && v <= 16) ctx->poolLdsEntries = v; }
     if (const char *env = getenv("RT_AMD_PATHS_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) ctx->pathsLeafBatch = v; }
     if (const char *env = getenv("RT_AMD_ACCEL_LDS_ENTRIES")) {
         const int v = atoi(env);
@@ -1408,8 +1150,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         S.aldsEntries = std::min(need, ctx->accelLdsEntries);
         S.aovfStride = (uint32_t)ctx->numCU * 8u * BLOCK;
         // overflow column per thread: the deeper deferred nodes, or the whole stack of an exact re-trace
-        const int ldsLeast = std::min(S.aldsEntries, ctx->poolLdsEntries);       // the pooled kernel keeps fewer slots in LDS
-        S.aovfRetrace = (uint32_t)std::max(need - ldsLeast, 0);
+        S.aovfRetrace = (uint32_t)std::max(need - S.aldsEntries, 0);
         const size_t ovfEntries = (size_t)(S.aovfRetrace + std::max(S.stackEntries, 1)) * S.aovfStride;
         HIP_TRY(ctx, hipMalloc(&ctx->dAOvf[0], ovfEntries * sizeof(uint32_t)));
         ctx->ovfBytes = ovfEntries * sizeof(uint32_t);      // the other slots' columns are allocated when a slot is first used
@@ -1588,14 +1329,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             SceneD Sp = S;
             Sp.leafBatch = ctx->pathsLeafBatch;
             Sp.aovf = ctx->dAOvf[si];       // concurrent launches must not share overflow columns
-            size_t ldsP = fast ? fast_stack_bytes(ctx) : lds;
-            const bool pooled = fast && ctx->pool != 0;
-            int launchBlocks = blocks;
-            if (pooled) {
-                Sp.aldsEntries = std::min(S.aldsEntries, ctx->poolLdsEntries);
-                ldsP = ((size_t)(Sp.aldsEntries + FAST_QUEUE_ENTRIES) * BLOCK + (size_t)(BLOCK / 64) * POOL_WAVE_WORDS) * sizeof(uint32_t);
-                launchBlocks = ctx->numCU * ctx->poolOcc;
-            }
+            const size_t ldsP = fast ? fast_stack_bytes(ctx) : lds;
             const int sobWords = B.nframes * F.maxBounces * 2;
             hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, ps, B, F.maxBounces, ctx->dSobolV, sl.dSobTable);
             HIP_TRY(ctx, hipMemsetAsync(sl.dWorkHead, 0, sizeof(uint32_t), ps));
@@ -1603,15 +1337,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, ps));
 #define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
-#define LAUNCH_POOL(N, O) hipLaunchKernelGGL((k_paths_pool<N, O>), dim3(launchBlocks), dim3(BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
-            if (pooled) {
-                if (cnt) { if (ctx->poolOcc == 4) LAUNCH_POOL(true, 4); else if (ctx->poolOcc == 6) LAUNCH_POOL(true, 6); else LAUNCH_POOL(true, 5); }
-                else if (ctx->poolOcc == 4) LAUNCH_POOL(false, 4);
-                else if (ctx->poolOcc == 6) LAUNCH_POOL(false, 6);
-                else LAUNCH_POOL(false, 5);
-            }
-#undef LAUNCH_POOL
-            else if (fast) {
+            if (fast) {
                 if (cnt) LAUNCH_PATHS(true, true, true, 5);
                 else if (occ == 5) LAUNCH_PATHS(true, true, false, 5);
                 else if (occ == 7) LAUNCH_PATHS(true, true, false, 7);
@@ -1732,8 +1458,7 @@ int rt_get_stats(RtContext *ctx, RtStats *out) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out->rays = wc.rays; out->node_tests = wc.node_tests; out->tri_tests = wc.tri_tests; out->tri_hits = wc.tri_hits;
     out->frames = ctx->frames;
-    out->retraced = wc.retraced & ((1ull << 60) - 1ull);
-    if (wc.retraced >> 60) return fail(ctx, RT_E_HIP, "rt_get_stats: a wave of the path kernel gave up after 30 s (watchdog); the images are incomplete");
+    out->retraced = wc.retraced;
     return RT_OK;
 }
 
