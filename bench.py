@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon1m", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=64,
-                    help="frames per step; the path kernel renders up to 64 frames per launch")
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="frames per step (default: 64, or the largest multiple of the workload's frames per launch "
+                         "below that: 63 at 4K, where a launch holds 21 frames)")
     ap.add_argument("--pipeline", default="persistent", choices=["wavefront", "megakernel", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
@@ -169,6 +170,9 @@ def main():
     info = r.scene_info()
 
     F, K, Wm = args.spp_per_step, args.steps, args.warmup
+    if F <= 0:
+        cap = info["frames_per_launch"]
+        F = 64 if cap >= 64 else max(cap, 64 // cap * cap)
     if args.total_spp:
         if args.total_spp % (world * K):
             raise SystemExit("--total-spp must be divisible by gpus * steps")
@@ -293,10 +297,12 @@ def main():
                          "bytes_per_ray_at_32B_per_box": round(binary_bpr, 1),
                          "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_local / max(launches, 1)),
                          "cache_served_tbps": round(achieved / 1e3, 3),
-                         "hbm_frac": (round(traffic / (kernel_ms / max(launches, 1) * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+                         "hbm_frac": (round(traffic / (kernel_ms * min(F, info["frames_per_launch"]) / (K * F) * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
                                       if traffic and kernel_ms > 0 else None),
-                         "hbm_note": "hbm_frac = PMC traffic beyond L2 per launch / launch time / 8 TB/s: an upper bound on the HBM share, "
-                                     "Infinity Cache hits are counted in it",
+                         "hbm_note": "hbm_frac = PMC traffic beyond L2 per full launch / time of a full launch / 8 TB/s: an upper bound on the "
+                                     "HBM share, Infinity Cache hits are counted in it",
+                         "timing_note": "kernel_ms_per_launch is the HIP-event time of each launch on its own stream; with overlap the end of "
+                                        "one launch and the start of the next share the GPU, so the sum can exceed the wall time",
                          "valu_issue_frac": pmc.get("valu_issue_frac_of_guide_peak") if pmc else None,
                          "valu_lane_utilisation": pmc.get("valu_lane_utilisation") if pmc else None,
                          "l2_hit_rate": pmc.get("l2_hit_rate") if pmc else None},
