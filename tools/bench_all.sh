@@ -13,6 +13,7 @@ python bench.py --no-cpu-baseline --no-call-granularity --pipeline wavefront --s
 python bench.py --no-cpu-baseline --no-call-granularity --workload sponza --total-spp 4096 --steps 8 --warmup 1 > $O/sponza_4096spp_strong.json 2>> $O/err.log || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-call-granularity > $GRAFT_REPO_ROOT/$O/dragon1m_under_rocprof.json 2>> $GRAFT_REPO_ROOT/$O/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_noov -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-call-granularity --no-overlap > $GRAFT_REPO_ROOT/$O/dragon1m_no_overlap_under_rocprof.json 2>> $GRAFT_REPO_ROOT/$O/err.log
 cd $GRAFT_REPO_ROOT
 for f in $O/*.json; do python3 - "$f" <<'PY'
 import json,sys
