@@ -132,6 +132,15 @@ typedef struct RtOptions {
                                RT_INDEX_BUILD_HOST (default): binned SAH on the host, the better index
                                (0.8 s for 1.3M triangles); RT_INDEX_BUILD_GPU: Morton-order tree built on the
                                device in milliseconds, more boxes per ray.  Same images either way. */
+    int32_t shading_normals; /* 0 (default): the reference's behaviour, the face normal of getTriangleNormal
+                               (frag:296-300).  1: an extension the reference only prepares - its Triangle
+                               carries n0 n1 n2 (frag:131, Model.h:101-112) and the comment on
+                               getTriangleNormal marks it "to be changed to interpolation": shade with
+                               the vertex normals RtTriangle.n interpolated at the hit point (weights =
+                               the three edge functions of hitTriangle, frag:265-275), normalised and
+                               turned to the side of the face normal; a triangle whose normals are zero
+                               keeps its face normal.  The scene must have been uploaded with this
+                               option already set (the normals are only copied to the GPU then). */
 } RtOptions;
 #define RT_INDEX_BUILD_HOST 0
 #define RT_INDEX_BUILD_GPU 1

@@ -97,6 +97,11 @@ typedef struct {
                                    int(f + 0.5) (frag:180-182), exact only below 2^23: it cannot express
                                    a tree of more than 4 194 304 triangles.  Callers set this for such
                                    trees only; everything else is read from the textures as usual. */
+    int shadingNormals;         /* 0: the reference's behaviour (the face normal of getTriangleNormal).
+                                   1: an extension the reference only prepares (the Triangle struct carries
+                                   n0 n1 n2, frag:131, and the comment above getTriangleNormal, frag:295,
+                                   marks it as to be changed to interpolation): shade with the
+                                   interpolated vertex normals, see shading_normal() below. */
 } OrScene;
 
 typedef struct {
@@ -166,7 +171,7 @@ typedef struct {                                                 /* frag:242-250
     float roughness, refraction, rayHitMin;
 } HitRecord;
 
-typedef struct { v3 v0, v1, v2, ka, kd, ks; } Tri;               /* used fields of frag:128-133 */
+typedef struct { v3 v0, v1, v2, ka, kd, ks, n0, n1, n2; } Tri;   /* used fields of frag:128-133; n0..n2 only with shadingNormals */
 
 typedef struct {
     const OrScene *sc;
@@ -267,6 +272,12 @@ static Tri get_triangle(const OrScene *sc, int offset) {
     t.ka = V3(At(T, W, o + 24), At(T, W, o + 25), At(T, W, o + 26));
     t.kd = V3(At(T, W, o + 27), At(T, W, o + 28), At(T, W, o + 29));
     t.ks = V3(At(T, W, o + 30), At(T, W, o + 31), At(T, W, o + 32));
+    t.n0 = t.n1 = t.n2 = V3(0.0f, 0.0f, 0.0f);
+    if (sc->shadingNormals) {
+        t.n0 = V3(At(T, W, o + 3), At(T, W, o + 4), At(T, W, o + 5));
+        t.n1 = V3(At(T, W, o + 11), At(T, W, o + 12), At(T, W, o + 13));
+        t.n2 = V3(At(T, W, o + 19), At(T, W, o + 20), At(T, W, o + 21));
+    }
     return t;
 }
 
@@ -312,6 +323,26 @@ static v3 triangle_normal(const Tri *tri, const Ray *r) {
     v3 res = normalize3(cross3(vsub(tri->v2, tri->v0), vsub(tri->v1, tri->v0)));
     if (dot3(res, r->direction) > 0.0f) res = vneg(res);
     return res;
+}
+
+/* shadingNormals = 1 (not in the reference, see OrScene).  The weights are the three edge
+ * functions hitTriangle evaluates (frag:265-275) taken at the hit position P: w0 belongs to v0
+ * (edge v1->v2), w1 to v1 (edge v2->v0), w2 to v2 (edge v0->v1); their common factor drops out
+ * in the normalisation.  The result is turned to the side of the (already flipped) face normal.
+ * A sum that is zero, infinite or NaN (a model without normals stores zeros) keeps the face normal. */
+static v3 shading_normal(const Tri *tri, v3 P, v3 faceNormal) {
+    v3 N = normalize3(cross3(vsub(tri->v1, tri->v0), vsub(tri->v2, tri->v0)));
+    float w2 = dot3(N, cross3(vsub(tri->v1, tri->v0), vsub(P, tri->v0)));
+    float w0 = dot3(N, cross3(vsub(tri->v2, tri->v1), vsub(P, tri->v1)));
+    float w1 = dot3(N, cross3(vsub(tri->v0, tri->v2), vsub(P, tri->v2)));
+    v3 n = V3(MADD(w2, tri->n2.x, MADD(w1, tri->n1.x, w0 * tri->n0.x)),
+              MADD(w2, tri->n2.y, MADD(w1, tri->n1.y, w0 * tri->n0.y)),
+              MADD(w2, tri->n2.z, MADD(w1, tri->n1.z, w0 * tri->n0.z)));
+    float l2 = dot3(n, n);
+    if (!(l2 > 0.0f) || !(l2 < INFINITY)) return faceNormal;
+    n = vscale(n, 1.0f / sqrtf(l2));
+    if (dot3(n, faceNormal) < 0.0f) n = vneg(n);
+    return n;
 }
 
 /* frag:306-331.  getBoundp(b,i) = i==0 ? pMin : pMax. */
@@ -380,6 +411,7 @@ static int hit_bvh(Px *p, Ray ray) {
         HitRecord *rec = &p->rec;
         rec->Pos = along(ray.origin, ray.hitMin, ray.direction);
         rec->Normal = triangle_normal(&tri, &ray);
+        if (sc->shadingNormals) rec->Normal = shading_normal(&tri, rec->Pos, rec->Normal);
         float temp = or_rand(p);
         if (sqrtf(dot3(tri.ka, tri.ka)) > 0.0f) {           /* length(tri.ka) > 0.0 */
             rec->materialIndex = 0;

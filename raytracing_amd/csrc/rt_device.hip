@@ -54,7 +54,7 @@ __device__ __forceinline__ void flush_counters(WorkCounters *wc, uint32_t rays, 
 // ------------------------------------------------------------------ megakernel
 
 // One thread per pixel, `count` frames per launch; accumulators stay in registers.
-template <bool CULL, bool COUNT>
+template <bool CULL, bool COUNT, bool VNRM = false>
 __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const FrameD F, const int firstLoopNum,
                                                       const int count, const float *__restrict__ randOrigin,
                                                       const uint32_t *__restrict__ sobV,
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
                 if (COUNT && tri != REF_NONE) cHit++;
                 float su, sv;
                 sobol_pair(sobV, loopNum, (uint32_t)b, su, sv);
-                if (!shade_hit(F, S, p, t, tri, b, su, sv, uvx, uvy, sample)) break;
+                if (!shade_hit<VNRM>(F, S, p, t, tri, b, su, sv, uvx, uvy, sample)) break;
             }
             // frag:697 with an fp32 history, and the plain sum
             const float n = (float)(int)loopNum;
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
 
 // shade: one thread per ray of the current queue; finished paths write their sample,
 // continuing paths are compacted into the next queue.
+template <bool VNRM>
 __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F, const int bounce, const uint32_t loopNum,
                                                  const uint32_t *__restrict__ sobV, const PathSoA Qin, const uint32_t cap, const uint32_t *__restrict__ qcountIn,
                                                  const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri,
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
             const float uvx = ((float)px + 0.5f) / (float)F.width;
             const float uvy = ((float)py + 0.5f) / (float)F.height;
             vec3 sample;
-            goOn = shade_hit(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, uvx, uvy, sample);
+            goOn = shade_hit<VNRM>(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, uvx, uvy, sample);
             if (!goOn && (sample.x != 0.0f || sample.y != 0.0f || sample.z != 0.0f)) {
                 const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
                 cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
@@ -399,7 +400,7 @@ __global__ void k_sobol_table(const BatchD B, const int maxBounces, const uint32
 //
 // FAST: closest hit through the search index with the proof/re-trace of k_extend_fast;
 // otherwise the reference's tree in the reference's order (Trav<CULL>).
-template <bool FAST, bool CULL, bool COUNT, int OCC>
+template <bool FAST, bool CULL, bool COUNT, int OCC, bool VNRM = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths(const SceneD S, const FrameD F, const BatchD B,
                                                  const float *__restrict__ sob, uint32_t *__restrict__ workHead, float *__restrict__ cur,
                                                  WorkCounters *__restrict__ wc) {
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                 Path p;
                 p.o = tv.o; p.d = tv.d; p.thr = thr; p.seed = seed;
                 vec3 sample;
-                const bool goOn = shade_hit(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], uvx, uvy, sample);
+                const bool goOn = shade_hit<VNRM>(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], uvx, uvy, sample);
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
@@ -677,6 +678,7 @@ struct RtContext {
 
     // scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
+    float4 *dVNrm = nullptr;            // vertex normals, only when the scene was uploaded with shading_normals set
     float4 *dANodes = nullptr;                                  // search index: nodes
     uint32_t *dAOvf[NSLOT] = {};                               // overflow of the deferred-node stack, one per launch slot
     int accelLdsEntries = 16;
@@ -967,6 +969,7 @@ int rt_default_options(RtOptions *out) {
     out->history8 = 0;
     out->overlap = 1;
     out->index_build = RT_INDEX_BUILD_HOST;
+    out->shading_normals = 0;
     return RT_OK;
 }
 
@@ -1042,7 +1045,7 @@ void rt_destroy(RtContext *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->freeEvents) hipEventDestroy(e);
-    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats);
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dVNrm);
     hipFree(ctx->dANodes);
     for (auto &p : ctx->dAOvf) hipFree(p);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
@@ -1073,6 +1076,8 @@ int rt_set_options(RtContext *ctx, const RtOptions *opt) {
     if (opt->max_bounces < 1 || opt->max_bounces > RT_MAX_BOUNCES) return fail(ctx, RT_E_INVALID, "rt_set_options: max_bounces must be in 1..8");
     if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL && opt->pipeline != RT_PIPELINE_PERSISTENT) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
     if (opt->index_build != RT_INDEX_BUILD_HOST && opt->index_build != RT_INDEX_BUILD_GPU) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown index_build");
+    if (opt->shading_normals != 0 && ctx->haveScene && !ctx->dVNrm)
+        return fail(ctx, RT_E_STATE, "rt_set_options: shading_normals needs a scene uploaded with the option already set");
     ctx->opt = *opt;
     ctx->frame.maxBounces = opt->max_bounces;
     return RT_OK;
@@ -1103,7 +1108,8 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes);
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dVNrm);
+    ctx->dVNrm = nullptr;
     for (auto &p : ctx->dAOvf) { hipFree(p); p = nullptr; }
     ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dANodes = nullptr; ctx->haveScene = false;
     const size_t nodeBytes = std::max<size_t>(hNodes.size(), 4) * sizeof(float4);
@@ -1114,6 +1120,19 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     HIP_TRY(ctx, hipMemcpy(ctx->dTris, hTris.data(), hTris.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dMats, hMats.data(), hMats.size() * sizeof(float4), hipMemcpyHostToDevice));
     S.nodes = ctx->dNodes; S.tris = ctx->dTris; S.mats = ctx->dMats;
+    if (ctx->opt.shading_normals) {
+        std::vector<float4> hVN((size_t)n * 3);
+        parallel_for(n, [&](int64_t ib, int64_t ie) {
+            for (int64_t i = ib; i < ie; i++) {
+                const RtTriangle &t = tris[i];
+                hVN[(size_t)i * 3 + 0] = make_float4(t.n[0][0], t.n[0][1], t.n[0][2], t.n[1][0]);
+                hVN[(size_t)i * 3 + 1] = make_float4(t.n[1][1], t.n[1][2], t.n[2][0], t.n[2][1]);
+                hVN[(size_t)i * 3 + 2] = make_float4(t.n[2][2], 0.0f, 0.0f, 0.0f);
+            }
+        });
+        HIP_TRY(ctx, hipMalloc(&ctx->dVNrm, hVN.size() * sizeof(float4)));
+        HIP_TRY(ctx, hipMemcpy(ctx->dVNrm, hVN.data(), hVN.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     S.anodes = nullptr; S.arootRef = REF_NONE; S.aovf = nullptr; S.aovfStride = 0; S.aovfRetrace = 0; S.aldsEntries = 1;
     uint32_t indexNodes = 0; int indexStackNeed = 0;
     if (haveAccel) {
@@ -1251,7 +1270,10 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     int rc = RT_OK;
     if (ctx->pendingEvents.size() > 8192) { rc = resolve_events(ctx); if (rc != RT_OK) return rc; }
     const FrameD &F = ctx->frame;
-    const SceneD &S = ctx->scene;
+    SceneD S = ctx->scene;
+    const bool vnrm = ctx->opt.shading_normals != 0;
+    if (vnrm && !ctx->dVNrm) return fail(ctx, RT_E_STATE, "rt_render_frames: shading_normals needs a scene uploaded with the option already set");
+    S.vnrm = vnrm ? ctx->dVNrm : nullptr;
     const int tiles = ((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
     const int tileBlocks = (tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     const size_t lds = stack_bytes(ctx);
@@ -1272,7 +1294,11 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
         HIP_TRY(ctx, hipEventRecord(e0, st));
 #define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters)
-        if (cull) { if (cnt) LAUNCH_MEGA(true, true); else LAUNCH_MEGA(true, false); }
+        if (vnrm) {     // shading with vertex normals: the counting instantiations only
+            if (cull) hipLaunchKernelGGL((k_megakernel<true, true, true>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters);
+            else hipLaunchKernelGGL((k_megakernel<false, true, true>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters);
+        }
+        else if (cull) { if (cnt) LAUNCH_MEGA(true, true); else LAUNCH_MEGA(true, false); }
         else { if (cnt) LAUNCH_MEGA(false, true); else LAUNCH_MEGA(false, false); }
 #undef LAUNCH_MEGA
         HIP_TRY(ctx, hipGetLastError());
@@ -1293,7 +1319,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         const bool overlap = ctx->opt.overlap != 0;
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
-        const int occ = paths_occupancy(ctx);
+        const int occ = vnrm ? 5 : paths_occupancy(ctx);
         const int blocks = ctx->numCU * (fast ? occ : 5);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
         if (overlap && !ctx->inputEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->inputEvent, hipEventDisableTiming));
@@ -1337,7 +1363,12 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, ps));
 #define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
-            if (fast) {
+#define LAUNCH_PATHS_VN(A, C) hipLaunchKernelGGL((k_paths<A, C, true, 5, true>), dim3(blocks), dim3(BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
+            if (vnrm) {     // shading with vertex normals: the counting instantiations only
+                if (fast) LAUNCH_PATHS_VN(true, true); else if (cull) LAUNCH_PATHS_VN(false, true); else LAUNCH_PATHS_VN(false, false);
+            }
+#undef LAUNCH_PATHS_VN
+            else if (fast) {
                 if (cnt) LAUNCH_PATHS(true, true, true, 5);
                 else if (occ == 5) LAUNCH_PATHS(true, true, false, 5);
                 else if (occ == 7) LAUNCH_PATHS(true, true, false, 7);
@@ -1396,8 +1427,10 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             }
             HIP_TRY(ctx, hipEventRecord(e1, st));
             ctx->pendingEvents.emplace_back(e0, e1);
-            hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
-                               ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
+            if (vnrm) hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
+                                         ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
+                                    ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
         }
         hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum,
                            counts, F.maxBounces, ctx->opt.history8, ctx->dCounters);

@@ -20,6 +20,8 @@
 //   mats:  one 80-byte record per triangle, read once per final hit: ka kd ks (frag:220-230),
 //          the shading normal (frag:296-300) and its tangent frame (frag:494-500), which depend
 //          on the triangle only.
+//   vnrm:  only with RtOptions.shading_normals: one 48-byte record per triangle, the vertex
+//          normals n0 n1 n2 (frag:131), read once per final hit.
 // The reference's 33-float triangle texel and 9-float node texel carry 15 resp. 0 floats the
 // shader never uses (normals, uvs: frag:196-218).
 #pragma once
@@ -40,6 +42,7 @@ struct SceneD {
     const float4 *nodes;    // 4 x float4 per interior node
     const float4 *tris;     // 4 x float4 per triangle
     const float4 *mats;     // 5 x float4 per triangle
+    const float4 *vnrm;     // RtOptions.shading_normals: 3 x float4 per triangle (n0 n1 n2 | pad), else nullptr
     float rootMin[3];
     float rootMax[3];
     uint32_t rootRef;       // LEAF_BIT|0 for a one-triangle scene, 0 otherwise, REF_NONE if empty
@@ -53,8 +56,7 @@ struct SceneD {
     int32_t aldsEntries;    // deferred-node slots per lane kept in LDS; deeper ones go to aovf
     uint32_t *aovf;         // overflow slots, [slot][thread of the grid]
     uint32_t aovfStride;
-    uint32_t aovfRetrace;   // first overflow slot of the exact re-trace's stack: above every slot a deferred node can take,
-                            // because a lane may re-trace a pooled ray while its own ray has nodes deferred there
+    uint32_t aovfRetrace;   // first overflow slot of the exact re-trace's stack: above every slot a deferred node can take
     float arootMin[3];
     float arootMax[3];
     float originLimit;      // rays starting farther than this from the origin skip the index

@@ -82,6 +82,9 @@ __host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tan
 // opens the next iteration (frag:625-630).  sobU/sobV are the frame's Sobol numbers for this
 // bounce (sobol_pair).  Returns true when the path goes on (p holds the next ray); otherwise
 // `sample` is the frame's radiance for the pixel.
+// VNRM: shade with interpolated vertex normals (RtOptions.shading_normals); kernels that do so
+// are separate instantiations, so the default ones pay neither registers nor branches for it.
+template <bool VNRM = false>
 __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
                                           int bounce, float sobU, float sobV, float uvx, float uvy, vec3 &sample) {
     sample = rtm::mk(0.0f, 0.0f, 0.0f);
@@ -102,6 +105,30 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
         bitangent = rtm::mk(m3.w, m4.x, m4.y);
         recFrame = true;
         if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
+        if constexpr (VNRM) {
+            // RtOptions.shading_normals: vertex normals interpolated with the edge functions of
+            // hitTriangle (frag:265-275) at the hit position, normalised, turned to the side of
+            // the face normal; a zero, infinite or NaN sum keeps the face normal
+            const float4 *g = S.tris + (size_t)tri * 4;
+            const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+            const float4 *vn = S.vnrm + (size_t)tri * 3;
+            const float4 a0 = vn[0], a1 = vn[1], a2 = vn[2];
+            const vec3 v0 = rtm::mk(g0.x, g0.y, g0.z), v1 = rtm::mk(g0.w, g1.x, g1.y), v2 = rtm::mk(g1.z, g1.w, g2.x);
+            const vec3 N = rtm::mk(g2.y, g2.z, g2.w);
+            const float w2 = rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pos, v0)));
+            const float w0 = rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pos, v1)));
+            const float w1 = rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pos, v2)));
+            vec3 n = rtm::mk(rtm::madd(w2, a1.z, rtm::madd(w1, a0.w, w0 * a0.x)),
+                             rtm::madd(w2, a1.w, rtm::madd(w1, a1.x, w0 * a0.y)),
+                             rtm::madd(w2, a2.x, rtm::madd(w1, a1.y, w0 * a0.z)));
+            const float l2 = rtm::dot(n, n);
+            if ((l2 > 0.0f) && (l2 < INFINITY)) {
+                n = rtm::scale(n, rtm::rsqrt_exact(l2));
+                if (rtm::dot(n, nrm) < 0.0f) n = rtm::neg(n);
+                nrm = n;
+                recFrame = false;
+            }
+        }
         const float temp = rand01(p.seed);                                      // frag:462
         const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
         const float ksx = m1.z, ksy = m1.w;

@@ -39,7 +39,8 @@ class OrScene(C.Structure):
                 ("width", C.c_int), ("height", C.c_int),
                 ("V", C.c_void_p),
                 ("sphere", OrSphere * 10), ("sphereNum", C.c_int),
-                ("maxBounces", C.c_int), ("trigMode", C.c_int), ("bvhInts", C.c_void_p)]
+                ("maxBounces", C.c_int), ("trigMode", C.c_int), ("bvhInts", C.c_void_p),
+                ("shadingNormals", C.c_int)]
 
 
 class OrStats(C.Structure):
@@ -131,7 +132,8 @@ class OracleScene:
     """Holds the reference-format textures and uniforms for the shader oracle."""
 
     def __init__(self, tex_tri, tex_tri_w, ntri, tex_bvh, tex_bvh_w, nnode, width, height,
-                 sobol_v, spheres=None, max_bounces=4, trig_mode=1, fused=True, bvh_ints=None):
+                 sobol_v, spheres=None, max_bounces=4, trig_mode=1, fused=True, bvh_ints=None,
+                 shading_normals=False):
         self.lib = load(fused)
         self._tt = np.ascontiguousarray(tex_tri, dtype=np.float32)
         self._tb = np.ascontiguousarray(tex_bvh, dtype=np.float32)
@@ -160,6 +162,7 @@ class OracleScene:
         s.trigMode = trig_mode
         self._ints = None if bvh_ints is None else np.ascontiguousarray(bvh_ints, dtype=np.int32)
         s.bvhInts = None if self._ints is None else self._ints.ctypes.data
+        s.shadingNormals = int(shading_normals)
         self.s = s
         self.width, self.height = width, height
 

@@ -582,6 +582,106 @@ def test_render_from_loaded_obj_files_with_reference_camera(golden_dir, tmp_path
     assert np.nan_to_num(want3).max() > 1.0
 
 
+def _globe_obj(path, nu=32, nv=16, missing_library=True):
+    """A latitude/longitude unit sphere as an OBJ with v/vt/vn corners: triangles at the north
+    pole, quads elsewhere; vn = the position (smooth normals)."""
+    lines = ["mtllib not-there.mtl" if missing_library else "", "o globe"]
+    for j in range(nv + 1):
+        for i in range(nu):
+            th, ph = np.pi * j / nv, 2.0 * np.pi * i / nu
+            x, y, z = np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)
+            lines += ["v %.6f %.6f %.6f" % (x, y, z), "vn %.4f %.4f %.4f" % (x, y, z), "vt %.4f %.4f" % (i / nu, j / nv)]
+    lines += ["usemtl b0b0b0", "s 1"]
+    idx = lambda i, j: j * nu + (i % nu) + 1
+    ntri = 0
+    for j in range(nv):
+        for i in range(nu):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            if j == 0:
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (a, a, a, c, c, c, d, d, d)); ntri += 1
+            else:
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d" % (a, a, a, b, b, b, c, c, c, d, d, d)); ntri += 2
+    open(path, "w").write("\n".join(lines) + "\n")
+    return ntri
+
+
+def test_render_model_shaped_like_the_references_globe(golden_dir, tmp_path):
+    """The reference's larger models (globe-sphere.obj, low-poly-fox) are `v/vt/vn` corners, quad and
+    triangle faces, one object, and - the globe - a material library that is not there.  A
+    latitude/longitude sphere written the same way, placed in the reference's room: loader ->
+    builder -> every pipeline against the oracle."""
+    import os
+    ntri = _globe_obj(str(tmp_path / "globe.obj"))
+    W, H = 150, 100
+    sc = rt.Scene()
+    sc.push_obj(os.path.join(golden_dir, "objects", "room.obj"), (5.0, 5.0, 5.0), (0.0, 5.0, 0.0))
+    sc.push_obj(str(tmp_path / "globe.obj"), (1.6, 1.6, 1.6), (-0.5, 2.0, 0.5))
+    t = sc.triangles()
+    assert t.shape[0] == 20 + ntri
+    assert np.allclose(t["kd"][20:], 0.6) and not t["ks"][20:].any() and t["n"][20:].any() and t["tex"][20:].any()
+    tris, nodes = rt.bvh_build(t)
+    cam = rt.CameraRig(W, H).uniforms()
+    ro = rt.rand_origins(20221003, 3)
+    want, st = _oracle_for(tris, nodes, W, H, None).render(cam, 1, ro, want_stats=True)
+    res = _render_all_pipelines(tris, nodes, cam, ro, W, H)
+    for name, (img, rays) in res.items():
+        assert _same_image(img, want), name
+        assert rays == st["rays"], name
+    assert np.nan_to_num(want).max() > 1.0
+
+
+def test_shading_with_interpolated_vertex_normals(golden_dir, tmp_path):
+    """RtOptions.shading_normals (the reference's Triangle carries n0 n1 n2, frag:131, but
+    getTriangleNormal, frag:296-300, still returns the face normal): every pipeline against the
+    oracle in the same mode; the image differs from the face-normal one on a smooth mirror ball;
+    triangles without normals (the room's file has `vn 0 -1 0` on every face, the procedural
+    scenes have zeros) keep their face normal; the option needs a scene uploaded with it set."""
+    import os
+    _globe_obj(str(tmp_path / "globe.obj"), missing_library=False)
+    (tmp_path / "globe.obj").write_text("mtllib ball.mtl\n" + (tmp_path / "globe.obj").read_text())
+    (tmp_path / "ball.mtl").write_text("newmtl b0b0b0\nKd 0.9 0.8 0.7\nKs 0.5 1.0 0\n")      # half diffuse, half mirror
+    W, H = 150, 100
+    sc = rt.Scene()
+    sc.push_obj(os.path.join(golden_dir, "objects", "room.obj"), (5.0, 5.0, 5.0), (0.0, 5.0, 0.0))
+    sc.push_obj(str(tmp_path / "globe.obj"), (1.8, 1.8, 1.8), (-0.5, 2.0, 0.5))
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.CameraRig(W, H).uniforms()
+    ro = rt.rand_origins(20221003, 3)
+    flat, _ = _oracle_for(tris, nodes, W, H, None).render(cam, 1, ro)
+    want, st = _oracle_for(tris, nodes, W, H, None, shading_normals=True).render(cam, 1, ro, want_stats=True)
+    assert not _same_image(flat, want)
+    for name, pipeline, accel in (("paths", rt.PIPELINE_PERSISTENT, True), ("paths_ref_order", rt.PIPELINE_PERSISTENT, False),
+                                  ("wavefront", rt.PIPELINE_WAVEFRONT, True), ("mega", rt.PIPELINE_MEGAKERNEL, False)):
+        r = rt.Renderer(W, H)
+        r.set_options(pipeline=pipeline, accel=accel, shading_normals=True)
+        r.upload(tris, nodes)
+        r.set_camera(cam)
+        r.render(1, ro)
+        assert _same_image(r.read_mean(), want), name
+        assert r.stats()["rays"] == st["rays"], name
+        # the same context with the option off again: the reference's normals
+        r.set_options(pipeline=pipeline, accel=accel, shading_normals=False)
+        r.reset()
+        r.render(1, ro)
+        assert _same_image(r.read_mean(), flat), name
+        r.close()
+    # zero normals: nothing to interpolate, the face normal stays
+    z = tris.copy(); z["n"] = 0.0
+    r = rt.Renderer(W, H)
+    r.set_options(shading_normals=True)
+    r.upload(z, nodes)
+    r.set_camera(cam)
+    r.render(1, ro)
+    assert _same_image(r.read_mean(), flat)
+    r.close()
+    # a scene uploaded without the option has no normals on the GPU
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    with pytest.raises(rt.RtError, match="shading_normals"):
+        r.set_options(shading_normals=True)
+    r.close()
+
+
 def test_sweep_built_tree_renders_like_the_oracle_on_the_same_tree():
     """The build mode the reference's author left commented out (BVH.h:225-256) gives another
     node order; the shader semantics on that tree are the same, so every pipeline must match the

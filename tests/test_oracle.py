@@ -96,3 +96,28 @@ def test_quirks_kept():
     assert (out == 0).all()
     # the reference re-traces a missed ray up to 3 more times (Russian roulette may stop it at i = 2, 3)
     assert st["rays"] == 256 and 2 * 256 <= st["raysRef"] <= 4 * 256 and st["raysRef"] > 3 * 256 * 0.8
+
+
+def test_shading_normal_mode_of_the_oracle():
+    """OrScene.shadingNormals: zero vertex normals leave every pixel as in the reference's mode;
+    vertex normals that tilt away from the face normal change diffuse pixels; a vertex normal
+    pointing to the back of the face is turned to the front."""
+    import raytracing_amd as rt
+    import scenes
+    W, H = 64, 40
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 2)
+    V = rt.sobol_default_table()
+    z = tris.copy(); z["n"] = 0.0
+    flat, _ = ol.scene_from_build(z, nodes, W, H, V, sc.spheres()).render(cam, 1, ro)
+    same, _ = ol.scene_from_build(z, nodes, W, H, V, sc.spheres(), shading_normals=True).render(cam, 1, ro)
+    assert np.array_equal(np.nan_to_num(flat), np.nan_to_num(same))
+    t = tris.copy()
+    t["n"][:, :, :] = np.array([0.3, 1.0, 0.2], dtype=np.float32)
+    tilted, _ = ol.scene_from_build(t, nodes, W, H, V, sc.spheres(), shading_normals=True).render(cam, 1, ro)
+    assert not np.array_equal(np.nan_to_num(flat), np.nan_to_num(tilted))
+    t["n"] *= -1.0
+    back, _ = ol.scene_from_build(t, nodes, W, H, V, sc.spheres(), shading_normals=True).render(cam, 1, ro)
+    assert np.array_equal(np.nan_to_num(back), np.nan_to_num(tilted))

@@ -155,3 +155,68 @@ def test_camera_default_and_from_angles():
         assert abs(np.linalg.norm(c3[v]) - 1) < 1e-6
     assert abs(np.dot(c3["front"], c3["right"])) < 1e-6 and abs(np.dot(c3["front"], c3["up"])) < 1e-6
     assert np.allclose(c3["leftbottom"], c3["front"] - c3["halfW"] * c3["right"] - c3["halfH"] * c3["up"], atol=1e-6)
+
+
+# ---- the reference's own model files (read where the reference lies; absent on a GPU box)
+
+REF_OBJECTS = "/root/reference/光线追踪/光线追踪/objects"
+
+
+def _parse_obj_independently(path):
+    """A second OBJ reader, written for this test only: positions of the fan-triangulated faces in
+    file order plus per-corner normals and (v-flipped) texture coordinates."""
+    V, VT, VN, P, N, T = [], [], [], [], [], []
+    for line in open(path, encoding="latin-1"):
+        w = line.split()
+        if not w:
+            continue
+        if w[0] == "v":
+            V.append([np.float32(x) for x in w[1:4]])
+        elif w[0] == "vt":
+            VT.append([np.float32(x) for x in w[1:3]])
+        elif w[0] == "vn":
+            VN.append([np.float32(x) for x in w[1:4]])
+        elif w[0] == "f":
+            cs = []
+            for tok in w[1:]:
+                f = (tok.split("/") + ["", ""])[:3]
+                vi = int(f[0]); ti = int(f[1]) if f[1] else 0; ni = int(f[2]) if f[2] else 0
+                vi = vi if vi > 0 else len(V) + 1 + vi
+                ti = ti if ti >= 0 else len(VT) + 1 + ti
+                ni = ni if ni >= 0 else len(VN) + 1 + ni
+                cs.append((vi, ti, ni))
+            for i in range(1, len(cs) - 1):
+                for c in (cs[0], cs[i], cs[i + 1]):
+                    P.append(V[c[0] - 1])
+                    N.append(VN[c[2] - 1] if c[2] else [0, 0, 0])
+                    T.append([VT[c[1] - 1][0], np.float32(1.0) - VT[c[1] - 1][1]] if c[1] else [0, 0])
+    shape = (len(P) // 3, 3)
+    return (np.array(P, np.float32).reshape(shape + (3,)), np.array(N, np.float32).reshape(shape + (3,)),
+            np.array(T, np.float32).reshape(shape + (2,)))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_OBJECTS), reason="the reference's model files are not on this machine")
+@pytest.mark.parametrize("name,ntri,kd,ks", [
+    ("low-poly-fox-by-pixelmannen.obj", 576, [1.0, 1.0, 1.0], [0.089804] * 3),     # triangles, v/vt/vn corners
+    ("globe-sphere.obj", 32040, [0.6, 0.6, 0.6], [0.0] * 3),     # 16020 quads; its mtllib names a file that does not exist
+    ("first-cube.obj", 54, None, None),                                            # two objects, two materials, quads and triangles
+])
+def test_reference_model_files(name, ntri, kd, ks):
+    """Model.h:54-182 on the models the reference ships besides room/cube: every face arrives,
+    fan-triangulated and in file order, with its corner normals and flipped texture
+    coordinates (Model.h:101-133) and the Ka/Kd/Ks of its material (Model.h:158-165); a missing
+    material library gives the importer's default material."""
+    path = os.path.join(REF_OBJECTS, name)
+    sc = rt.Scene()
+    sc.push_obj(path, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    t = sc.triangles()
+    P, N, T = _parse_obj_independently(path)
+    assert t.shape[0] == ntri == P.shape[0]
+    assert np.array_equal(t["v"], P) and np.array_equal(t["n"], N) and np.array_equal(t["tex"], T)
+    if kd is not None:
+        assert np.allclose(t["kd"], kd, atol=1e-6) and np.allclose(t["ks"], ks, atol=1e-6) and not t["ka"].any()
+    else:
+        assert len(np.unique(t["kd"], axis=0)) == 2      # one material per object
+    # the builder takes it like any other triangle list
+    tris, nodes = rt.bvh_build(t)
+    assert nodes.shape[0] == 2 * ntri - 1 and tris.shape[0] == ntri
