@@ -103,13 +103,13 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
 
 // Reserves consecutive queue slots for the lanes of this wave that pass `want`.
 __device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool want) {
-    const unsigned long long mask = __ballot(want);
+    const unsigned long long mask = ballot64(want);
     const uint32_t lane = threadIdx.x & 63;
     uint32_t base = 0;
     if (mask != 0ull) {
         const int leader = __ffsll((long long)mask) - 1;
         if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // scalar: the chunk bookkeeping stays wave uniform
     }
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA 
     uint32_t n = qcount[shard * CTL_STRIDE];
     bool more = true;                                   // wave-uniform: some shard may still hold rays
     while (true) {
-        const unsigned long long idle = __ballot(!have);
+        const unsigned long long idle = ballot64(!have);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (more && (nIdle >= (uint32_t)S.refill)) {
             uint32_t base = 0;
             const int leader = __ffsll((long long)idle) - 1;
             if ((int)lane == leader) base = atomicAdd(qhead + shard * CTL_STRIDE, nIdle);
-            base = __shfl(base, leader);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // scalar: the chunk bookkeeping stays wave uniform
             if (base >= n) {                            // this shard is drained: move on
                 k++;
                 if (k == NSHARD) more = false;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(const SceneD S, const PathSoA 
                 have = true;
             }
         }
-        if (__ballot(have) == 0ull) {
+        if (ballot64(have) == 0ull) {
             if (!more) break;
             continue;
         }
@@ -238,16 +238,16 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
     while (true) {
         // ---- finish + refill
         const bool fin = have && tv.finished();
-        const unsigned long long freeMask = __ballot(!have || fin);
+        const unsigned long long freeMask = ballot64(!have || fin);
         const uint32_t nFree = (uint32_t)__popcll(freeMask);
-        const unsigned long long busyMask = __ballot(have && !fin);
+        const unsigned long long busyMask = ballot64(have && !fin);
         if ((more && nFree >= (uint32_t)S.refill) || busyMask == 0ull) {
             bool exact = false;
             if (fin) {
                 exact = tv.tie || !tv.usable(S);
                 if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
             }
-            if (__ballot(exact) != 0ull) {
+            if (ballot64(exact) != 0ull) {
                 // Rare (a few rays per million): trace those rays again in the reference's order,
                 // right here.  The wave's other lanes wait; the other waves of the CU do not.
                 // The lane's global overflow column is empty at this point and serves as the stack.
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
                 uint32_t base = 0;
                 const int leader = __ffsll((long long)freeMask) - 1;
                 if ((int)lane == leader) base = atomicAdd(qhead + shard * CTL_STRIDE, nFree);
-                base = __shfl(base, leader);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // scalar: the chunk bookkeeping stays wave uniform
                 if (base >= n) {                        // this shard is drained: move on
                     k++;
                     if (k == NSHARD) more = false;
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
         const bool step = have && tv.can_step();
         if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
         // ---- triangle pass
-        const unsigned long long waiting = __ballot(have && tv.wants_test());
-        const unsigned long long stepping = __ballot(have && tv.can_step());
+        const unsigned long long waiting = ballot64(have && tv.wants_test());
+        const unsigned long long stepping = ballot64(have && tv.can_step());
         if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
             if (have && tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
         }
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
     tv.cur = REF_NONE;
     if constexpr (FAST) tv.npend = 0;
     bool have = false;
+    unsigned long long haveMask = 0ull;                 // wave-uniform: the lanes with `have` set (changes in the finish block only)
     uint32_t pix = 0;                                   // px | py << bitsX | frame slot << (bitsX + bitsY)
     const uint32_t maskX = (1u << B.bitsX) - 1u, maskY = (1u << B.bitsY) - 1u;
     const int shiftSlot = B.bitsX + B.bitsY;
@@ -441,17 +442,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
 #endif
     while (true) {
 #ifdef RT_EXP_PROFILE
-        xIter += 1ull + ((unsigned long long)__popcll(__ballot(have)) << 32);
+        xIter += 1ull + ((unsigned long long)__popcll(ballot64(have)) << 32);
 #endif
 #ifdef RT_EXP_TIMELINE
         tlIter++;
         if (exhausted && cNext >= cEnd && tlExhausted == 0) tlExhausted = wall_clock64();
 #endif
+        // wave-wide masks from fresh compares and scalar logic (a ballot of a derived lane mask costs two
+        // vector instructions; blocks are whole waves, so every lane is here)
         bool fin;
-        if constexpr (FAST) fin = have && tv.finished(); else fin = have && tv.done();
-        const uint32_t nFin = (uint32_t)__popcll(__ballot(fin));
-        const uint32_t nEmpty = (uint32_t)__popcll(__ballot(!have));
-        const unsigned long long busyMask = __ballot(have && !fin);
+        unsigned long long finMask;
+        if constexpr (FAST) {
+            fin = have && tv.finished();
+            finMask = ballot64(tv.cur == REF_NONE) & ballot64(tv.npend == 0) & haveMask;
+        } else {
+            fin = have && tv.done();
+            finMask = ballot64(tv.cur == REF_NONE) & haveMask;
+        }
+        const uint32_t nFin = (uint32_t)__popcll(finMask);
+        const uint32_t nEmpty = 64u - (uint32_t)__popcll(haveMask);
+        const unsigned long long busyMask = haveMask & ~finMask;
         const bool more = !exhausted || cNext < cEnd;
         bool go = busyMask == 0ull;
         if (more) go = go || (nFin + nEmpty >= (uint32_t)S.refill);
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                     exact = tv.tie || !tv.usable(S);
                     if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
                 }
-                if (__ballot(exact) != 0ull) {
+                if (ballot64(exact) != 0ull) {
                     if (exact) {
                         float t; uint32_t tri;
                         closest_triangle<true, COUNT>(S, tv.o, tv.d, ovf + (size_t)S.aovfRetrace * S.aovfStride, (int)S.aovfStride, t, tri, cNode, cTri);
@@ -507,13 +517,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
             // items for the idle lanes (a second round when the wave's chunk ran out half way)
             uint32_t item = 0xFFFFFFFFu;
             for (int round = 0; round < 2; round++) {
-                const unsigned long long freeMask = __ballot(!have && item == 0xFFFFFFFFu);
+                const unsigned long long freeMask = ballot64(!have && item == 0xFFFFFFFFu);
                 if (freeMask == 0ull || (exhausted && cNext >= cEnd)) break;
                 if (cNext >= cEnd) {
                     uint32_t base = 0;
                     const int leader = __ffsll((long long)freeMask) - 1;
                     if ((int)lane == leader) base = atomicAdd(workHead, chunk);
-                    base = __shfl(base, leader);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // scalar: the chunk bookkeeping stays wave uniform
                     if (base >= total) { exhausted = true; break; }
                     cNext = base;
                     cEnd = (total - base < chunk) ? total : base + chunk;
@@ -545,25 +555,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
             if (startRay) {
                 if constexpr (FAST) tv.begin(S, stack, BLOCK, nextO, nextD, cNode); else tv.begin(S, nextO, nextD, cNode);
             }
-            if (__ballot(have) == 0ull) {
+            {   // the value is wave uniform; saying so keeps it in scalar registers across the loop
+                const unsigned long long m = ballot64(have);
+                haveMask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            }
+            if (haveMask == 0ull) {
                 if (exhausted && cNext >= cEnd) break;
                 continue;
             }
         }
         // ---- advance the rays by one step
         if constexpr (FAST) {
-            const bool step = have && tv.can_step();
+            // a lane without a path keeps cur == REF_NONE and an empty queue, so none of these needs `have`
+            const bool step = tv.can_step();
 #ifdef RT_EXP_PROFILE
-            { const unsigned long long ms = __ballot(step); if (ms) xNode += 1ull + ((unsigned long long)__popcll(ms) << 32); }
+            { const unsigned long long ms = ballot64(step); if (ms) xNode += 1ull + ((unsigned long long)__popcll(ms) << 32); }
 #endif
             if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
-            const unsigned long long waiting = __ballot(have && tv.wants_test());
-            const unsigned long long stepping = __ballot(have && tv.can_step());
+            const unsigned long long waiting = ballot64(tv.wants_test());
+            const unsigned long long stepping = ballot64(tv.can_step());
             if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
 #ifdef RT_EXP_PROFILE
-                xTest += 1ull + ((unsigned long long)__popcll(__ballot(have && tv.npend > 0)) << 32);
+                xTest += 1ull + ((unsigned long long)__popcll(ballot64(tv.npend > 0)) << 32);
 #endif
-                if (have && tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
+                if (tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
             }
         } else {
             if (have) {

@@ -38,6 +38,10 @@ using rtm::vec3;
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;     // also "no triangle"
 
+// Lanes of the wave for which p holds.  HIP's __ballot takes an int, which costs a
+// v_cndmask + v_cmp round trip for every predicate that is not already a fresh compare.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 struct SceneD {
     const float4 *nodes;    // 4 x float4 per interior node
     const float4 *tris;     // 4 x float4 per triangle

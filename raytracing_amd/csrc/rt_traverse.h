@@ -180,8 +180,8 @@ __device__ __forceinline__ void closest_triangle(const SceneD &S, const vec3 o, 
     Trav<CULL, COUNT> tv;
     tv.begin(S, o, d, nNode);
     while (true) {
-        const unsigned long long mI = __ballot(tv.at_interior());
-        const unsigned long long mL = __ballot(tv.at_leaf());
+        const unsigned long long mI = ballot64(tv.at_interior());
+        const unsigned long long mL = ballot64(tv.at_leaf());
         if ((mI | mL) == 0ull) break;
         wave_advance(tv, S, stack, stride, nNode, nTri, mI, mL);
     }
