@@ -172,7 +172,6 @@ void collapse_wide(const Builder &b, uint32_t root, Accel &out) {
         for (int c = 0; c < n; c++) nb.grow(ch[c].box);
         WideNode w;
         std::memset(&w, 0, sizeof w);
-        w.exps = 0;
         double scale[3];
         for (int k = 0; k < 3; k++) {
             w.origin[k] = nb.mn[k];
@@ -181,7 +180,7 @@ void collapse_wide(const Builder &b, uint32_t root, Accel &out) {
             e = std::min(std::max(e, -100), 100);
             while (255.0 * std::ldexp(1.0, e) < ext) e++;
             scale[k] = std::ldexp(1.0, e);
-            w.exps |= (uint32_t)(e + 127) << (8 * k);
+            (k == 0 ? w.scaleX : (k == 1 ? w.scaleY : w.scaleZ)) = (float)scale[k];
         }
         for (int c = 0; c < 4; c++) {
             if (c >= n) {

@@ -22,16 +22,16 @@ static_assert(sizeof(AccelNode) == 64, "AccelNode layout");
 // 4-wide node of the index as the GPU reads it (64 bytes).  The boxes of up to four children are
 // stored as 8-bit offsets from the node's own box corner, on a per-axis power-of-two grid, and
 // are rounded outwards, so the quantised boxes contain the (already grown) child boxes.
-//   decode: lo = origin[k] + qlo * 2^(exp_k - 127), hi = origin[k] + qhi * 2^(exp_k - 127)
+//   decode: lo = origin[k] + qlo * scale_k, hi = origin[k] + qhi * scale_k (scale_k a power of two)
 // qlo[k]/qhi[k] hold one byte per child (child c in bits 8c..8c+7); an empty slot has
 // ref == 0xFFFFFFFF and an inverted box (qlo 255, qhi 0).
 struct WideNode {
     float origin[3];
-    uint32_t exps;          // exp_x | exp_y << 8 | exp_z << 16 (biased float exponents)
+    float scaleX;           // the powers of two 2^exp_k as floats: scaleX here, scaleY and scaleZ at the end
     uint32_t ref[4];        // interior: index into the wide node array; leaf: LEAF | triangle number
     uint32_t qlo[3];
     uint32_t qhi[3];
-    uint32_t pad[2];
+    float scaleY, scaleZ;
 };
 static_assert(sizeof(WideNode) == 64, "WideNode layout");
 

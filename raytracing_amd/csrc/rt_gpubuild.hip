@@ -196,9 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_collapse(const int level, const uint2
         for (int c = 1; c < m; c++)
             for (int k = 0; k < 3; k++) { nb.mn[k] = fminf(nb.mn[k], box[c].mn[k]); nb.mx[k] = fmaxf(nb.mx[k], box[c].mx[k]); }
         WideNode w;
-        w.exps = 0u;
         for (int k = 0; k < 3; k++) { w.qlo[k] = 0u; w.qhi[k] = 0u; }
-        w.pad[0] = w.pad[1] = 0u;
         double scale[3];
         for (int k = 0; k < 3; k++) {
             w.origin[k] = nb.mn[k];
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void k_collapse(const int level, const uint2
             e = e < -100 ? -100 : (e > 100 ? 100 : e);
             while (255.0 * ldexp(1.0, e) < ext) e++;
             scale[k] = ldexp(1.0, e);
-            w.exps |= (uint32_t)(e + 127) << (8 * k);
+            (k == 0 ? w.scaleX : (k == 1 ? w.scaleY : w.scaleZ)) = (float)scale[k];
         }
         for (int c = 0; c < 4; c++) {
             if (c >= m) {

@@ -232,7 +232,7 @@ struct FastTrav {
     }
     __device__ __forceinline__ uint32_t unqueue_triangle(const uint32_t *col, const int stride) {
         npend--;
-        return col[npend * stride];
+        return col[npend * stride] & ~LEAF_BIT;
     }
     // deferred nodes: LDS column of this lane first, global overflow beyond S.aldsEntries
     __device__ __forceinline__ void push(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t v) {
@@ -262,7 +262,7 @@ struct FastTrav {
         // a ray with a zero, NaN or infinite direction component is not searched here at all
         // (with NaN every box would count as hit); the caller sends it to the exact path
         if (!(tn > tf) && !(tf < 0.0f) && !(tn > hitCull) && usable(S)) {
-            if (S.arootRef & LEAF_BIT) queue_triangle(col, stride, S.arootRef & ~LEAF_BIT);     // one-triangle scene
+            if (S.arootRef & LEAF_BIT) queue_triangle(col, stride, S.arootRef);     // one-triangle scene
             else cur = S.arootRef;
         }
     }
@@ -278,10 +278,9 @@ struct FastTrav {
     __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t &nNode) {
         const float4 *rec = S.anodes + (size_t)cur * 4;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        const uint32_t exps = __float_as_uint(q0.w);
-        const float Ax = __uint_as_float((exps & 0xFFu) << 23) * inv.x, Bx = (q0.x - o.x) * inv.x;
-        const float Ay = __uint_as_float(((exps >> 8) & 0xFFu) << 23) * inv.y, By = (q0.y - o.y) * inv.y;
-        const float Az = __uint_as_float(((exps >> 16) & 0xFFu) << 23) * inv.z, Bz = (q0.z - o.z) * inv.z;
+        const float Ax = q0.w * inv.x, Bx = (q0.x - o.x) * inv.x;
+        const float Ay = q3.z * inv.y, By = (q0.y - o.y) * inv.y;
+        const float Az = q3.w * inv.z, Bz = (q0.z - o.z) * inv.z;
         const uint32_t lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
         const uint32_t hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
         const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
@@ -299,10 +298,10 @@ struct FastTrav {
 #undef RT_CHILD
         if (COUNT) nNode += 4;
         // hit leaf children are queued for the triangle pass
-        if (live0 && (r0 & LEAF_BIT)) queue_triangle(col, stride, r0 & ~LEAF_BIT);
-        if (live1 && (r1 & LEAF_BIT)) queue_triangle(col, stride, r1 & ~LEAF_BIT);
-        if (live2 && (r2 & LEAF_BIT)) queue_triangle(col, stride, r2 & ~LEAF_BIT);
-        if (live3 && (r3 & LEAF_BIT)) queue_triangle(col, stride, r3 & ~LEAF_BIT);
+        if (live0 && (r0 & LEAF_BIT)) queue_triangle(col, stride, r0);      // stored with the leaf bit, removed when taken out
+        if (live1 && (r1 & LEAF_BIT)) queue_triangle(col, stride, r1);
+        if (live2 && (r2 & LEAF_BIT)) queue_triangle(col, stride, r2);
+        if (live3 && (r3 & LEAF_BIT)) queue_triangle(col, stride, r3);
         // hit interior children, farthest first (the others sort last)
         const bool in0 = live0 && !(r0 & LEAF_BIT), in1 = live1 && !(r1 & LEAF_BIT);
         const bool in2 = live2 && !(r2 & LEAF_BIT), in3 = live3 && !(r3 & LEAF_BIT);
