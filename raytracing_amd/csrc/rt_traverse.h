@@ -288,23 +288,34 @@ struct FastTrav {
         const uint32_t nry = ngy ? hiy : loy, fry = ngy ? loy : hiy;
         const uint32_t nrz = ngz ? hiz : loz, frz = ngz ? loz : hiz;
         uint32_t r0 = __float_as_uint(q1.x), r1 = __float_as_uint(q1.y), r2 = __float_as_uint(q1.z), r3 = __float_as_uint(q1.w);
-        // per child: clamped entry distance and whether the box is hit
-#define RT_CHILD(sh, k, live, r) \
+        // per child: clamped entry distance and whether the box is hit.  An empty slot (REF_NONE) has an
+        // inverted box, but a ray for which that box still counts as hit (infinite or NaN distances) must
+        // not follow it: as a signed number REF_NONE is -1, interior refs are >= 0, leaf refs < -1.
+#define RT_CHILD(sh, k, hit) \
         const float k = fmaxf(fmaxf(rtm::madd((float)((nrx >> sh) & 0xFFu), Ax, Bx), fmaxf(rtm::madd((float)((nry >> sh) & 0xFFu), Ay, By), \
                                     rtm::madd((float)((nrz >> sh) & 0xFFu), Az, Bz))), 0.0f); \
-        const bool live = !(k > fminf(fminf(rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), fminf(rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), \
-                                    rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz))), hitCull)) && (r != REF_NONE);
-        RT_CHILD(0, t0, live0, r0) RT_CHILD(8, t1, live1, r1) RT_CHILD(16, t2, live2, r2) RT_CHILD(24, t3, live3, r3)
+        const bool hit = !(k > fminf(fminf(rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), fminf(rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), \
+                                    rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz))), hitCull));
+        RT_CHILD(0, t0, hit0) RT_CHILD(8, t1, hit1) RT_CHILD(16, t2, hit2) RT_CHILD(24, t3, hit3)
 #undef RT_CHILD
         if (COUNT) nNode += 4;
-        // hit leaf children are queued for the triangle pass
-        if (live0 && (r0 & LEAF_BIT)) queue_triangle(col, stride, r0);      // stored with the leaf bit, removed when taken out
-        if (live1 && (r1 & LEAF_BIT)) queue_triangle(col, stride, r1);
-        if (live2 && (r2 & LEAF_BIT)) queue_triangle(col, stride, r2);
-        if (live3 && (r3 & LEAF_BIT)) queue_triangle(col, stride, r3);
+        // hit leaf children are queued for the triangle pass (stored with the leaf bit, removed when taken out)
+        // Without branches: every child is written at the slot the next queued one would take, so a
+        // child that is not queued is overwritten by the next one that is, or stays above the top
+        // (a step is only taken with npend <= PEND_MAX - 4, so all four slots exist).
+        {
+            const int c0 = (hit0 && (int32_t)r0 < -1) ? 1 : 0, c1 = (hit1 && (int32_t)r1 < -1) ? 1 : 0;
+            const int c2 = (hit2 && (int32_t)r2 < -1) ? 1 : 0, c3 = (hit3 && (int32_t)r3 < -1) ? 1 : 0;
+            uint32_t *q = col + npend * stride;
+            q[0] = r0; q += c0 * stride;
+            q[0] = r1; q += c1 * stride;
+            q[0] = r2; q += c2 * stride;
+            q[0] = r3;
+            npend += c0 + c1 + c2 + c3;
+        }
         // hit interior children, farthest first (the others sort last)
-        const bool in0 = live0 && !(r0 & LEAF_BIT), in1 = live1 && !(r1 & LEAF_BIT);
-        const bool in2 = live2 && !(r2 & LEAF_BIT), in3 = live3 && !(r3 & LEAF_BIT);
+        const bool in0 = hit0 && (int32_t)r0 >= 0, in1 = hit1 && (int32_t)r1 >= 0;
+        const bool in2 = hit2 && (int32_t)r2 >= 0, in3 = hit3 && (int32_t)r3 >= 0;
         float k0 = in0 ? t0 : -INFINITY, k1 = in1 ? t1 : -INFINITY, k2 = in2 ? t2 : -INFINITY, k3 = in3 ? t3 : -INFINITY;
         const int m = (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
 #define RT_CSWAP(ka, ra, kb, rb) { const bool sw = kb > ka; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
