@@ -573,8 +573,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
             { const unsigned long long ms = ballot64(step); if (ms) xNode += 1ull + ((unsigned long long)__popcll(ms) << 32); }
 #endif
             if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
-            const unsigned long long waiting = ballot64(tv.wants_test());
-            const unsigned long long stepping = ballot64(tv.can_step());
+            // wants_test() and can_step() of every lane, from three compares and scalar logic
+            const unsigned long long mNone = ballot64(tv.cur == REF_NONE);
+            const unsigned long long mFull = ballot64(tv.npend > FastTrav<COUNT>::PEND_MAX - 4);
+            const unsigned long long mPend = ballot64(tv.npend > 0);
+            const unsigned long long waiting = mPend & (mNone | mFull);
+            const unsigned long long stepping = ~(mNone | mFull);
             if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
 #ifdef RT_EXP_PROFILE
                 xTest += 1ull + ((unsigned long long)__popcll(ballot64(tv.npend > 0)) << 32);

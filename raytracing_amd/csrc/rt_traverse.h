@@ -242,7 +242,16 @@ struct FastTrav {
     }
     __device__ __forceinline__ uint32_t pop(const SceneD &S, const uint32_t *col, const int stride, const uint32_t *ovf) {
         sp--;
-        return (sp < S.aldsEntries) ? col[(PEND_MAX + sp) * stride] : ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride];
+        // the empty asm keeps the LDS read and the (rare) global read apart; merged, they become one
+        // flat load of a selected address
+        uint32_t v;
+        if (sp < S.aldsEntries) {
+            v = col[(PEND_MAX + sp) * stride];
+            asm volatile("" : "+v"(v));
+        } else {
+            v = ovf[(size_t)(sp - S.aldsEntries) * S.aovfStride];
+        }
+        return v;
     }
 
     __device__ __forceinline__ void begin(const SceneD &S, uint32_t *col, const int stride, const vec3 o_, const vec3 d_, uint32_t &nNode) {
