@@ -408,7 +408,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
     uint32_t *stack = lds_dyn + threadIdx.x;
     uint32_t *ovf = FAST ? S.aovf + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t tilesX = (uint32_t)(F.width + 7) >> 3, tilesY = (uint32_t)(F.height + 7) >> 3;
     const uint32_t framePix = tilesX * tilesY * 64u;
     const uint32_t total = framePix * (uint32_t)B.nframes;
@@ -432,6 +431,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
     vec3 thr = rtm::mk(0.0f, 0.0f, 0.0f);
     uint32_t seed = 0;
     uint32_t cNext = 0, cEnd = 0;                       // wave-uniform: the wave's current chunk of items
+    uint32_t cSlot = 0, cTy = 0, cTx = 0, cLane = 0;    // wave-uniform: where item cNext lies (frame slot, tile row/column, pixel of the 8x8 tile)
     // first chunk: a quarter of a wave's share of the batch, 64..256 items (a one-frame launch has
     // only ~290 items per wave; handing out 256 at once leaves nothing to balance with)
     uint32_t chunk = (total / (4u * nWaves)) & ~63u;
@@ -514,10 +514,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                     have = false;
                 }
             }
-            // items for the idle lanes (a second round when the wave's chunk ran out half way)
-            uint32_t item = 0xFFFFFFFFu;
+            // items for the idle lanes (a second round when the wave's chunk ran out half way).  The
+            // position of item cNext - frame slot, tile row, tile column, pixel within the tile - is kept
+            // in scalar registers and advanced with the counter, so a lane only adds its rank to it.
+            bool gotItem = false;
+            uint32_t iSlot = 0, iPx = 0, iPy = 0;
             for (int round = 0; round < 2; round++) {
-                const unsigned long long freeMask = ballot64(!have && item == 0xFFFFFFFFu);
+                const unsigned long long freeMask = ballot64(!have && !gotItem);
                 if (freeMask == 0ull || (exhausted && cNext >= cEnd)) break;
                 if (cNext >= cEnd) {
                     uint32_t base = 0;
@@ -527,6 +530,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                     if (base >= total) { exhausted = true; break; }
                     cNext = base;
                     cEnd = (total - base < chunk) ? total : base + chunk;
+                    cSlot = base / framePix;
+                    const uint32_t rem = base - cSlot * framePix, tile = rem >> 6;
+                    cLane = rem & 63u;
+                    cTy = tile / tilesX;
+                    cTx = tile - cTy * tilesX;
                     // guided self-scheduling: about half a share of what is left, 64..256 items
                     const uint32_t share = ((total - cEnd) / (2u * nWaves)) & ~63u;
                     chunk = share < 64u ? 64u : (share > 256u ? 256u : share);
@@ -534,22 +542,32 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                 const uint32_t nFree = (uint32_t)__popcll(freeMask);
                 const uint32_t left = cEnd - cNext;
                 const uint32_t give = nFree < left ? nFree : left;
-                const uint32_t rank = (uint32_t)__popcll(freeMask & below);
-                if (!have && item == 0xFFFFFFFFu && rank < give) item = cNext + rank;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeMask, 0u));
+                if (!have && !gotItem && rank < give) {
+                    gotItem = true;
+                    const uint32_t l = cLane + rank;                // < 128: at most one carry into the tile column
+                    uint32_t tx = cTx + (l >> 6), ty = cTy;
+                    iSlot = cSlot;
+                    if (tx >= tilesX) { tx = 0u; ty++; }
+                    if (ty >= tilesY) { ty = 0u; iSlot++; }
+                    iPx = tx * 8u + (l & 7u);
+                    iPy = ty * 8u + ((l >> 3) & 7u);
+                }
                 cNext += give;
+                cLane += give;                                      // give <= 64
+                if (cLane >= 64u) {
+                    cLane -= 64u;
+                    if (++cTx >= tilesX) { cTx = 0u; if (++cTy >= tilesY) { cTy = 0u; cSlot++; } }
+                }
                 if (give == nFree) break;
             }
-            if (item != 0xFFFFFFFFu) {
-                const uint32_t slot = item / framePix, rem = item - slot * framePix;
-                uint32_t px, py;
-                if (tile_pixel((int)(rem >> 6), (int)(rem & 63u), F.width, F.height, px, py)) {
-                    Path p; float uvx, uvy;
-                    generate_path(F, B.randOrigin[slot], px, py, p, uvx, uvy);
-                    thr = p.thr; seed = p.seed; bounce = 0;
-                    pix = px | (py << B.bitsX) | (slot << shiftSlot);
-                    nextO = p.o; nextD = p.d; startRay = true;
-                    have = true;
-                }
+            if (gotItem && iPx < (uint32_t)F.width && iPy < (uint32_t)F.height) {
+                Path p; float uvx, uvy;
+                generate_path(F, B.randOrigin[iSlot], iPx, iPy, p, uvx, uvy);
+                thr = p.thr; seed = p.seed; bounce = 0;
+                pix = iPx | (iPy << B.bitsX) | (iSlot << shiftSlot);
+                nextO = p.o; nextD = p.d; startRay = true;
+                have = true;
             }
             // continued and new paths start their rays together
             if (startRay) {
