@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
                 if (COUNT && tri != REF_NONE) cHit++;
                 float su, sv;
                 sobol_pair(sobV, loopNum, (uint32_t)b, su, sv);
-                if (!shade_hit<VNRM>(F, S, p, t, tri, b, su, sv, uvx, uvy, sample)) break;
+                if (!shade_hit<VNRM>(F, S, p, t, tri, b, su, sv, px, py, sample)) break;
             }
             // frag:697 with an fp32 history, and the plain sum
             const float n = (float)(int)loopNum;
@@ -326,10 +326,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
             p.seed = Qin.seed[slot];
             pix = Qin.pix[slot];
             const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
-            const float uvx = ((float)px + 0.5f) / (float)F.width;
-            const float uvy = ((float)py + 0.5f) / (float)F.height;
             vec3 sample;
-            goOn = shade_hit<VNRM>(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, uvx, uvy, sample);
+            goOn = shade_hit<VNRM>(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, px, py, sample);
             if (!goOn && (sample.x != 0.0f || sample.y != 0.0f || sample.z != 0.0f)) {
                 const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
                 cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
@@ -497,19 +495,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
                 cRays++;
                 if (COUNT && tv.best != REF_NONE) cHit++;
                 const uint32_t px = pix & maskX, py = (pix >> B.bitsX) & maskY, slot = pix >> shiftSlot;
-                const float uvx = ((float)px + 0.5f) / (float)F.width;
-                const float uvy = ((float)py + 0.5f) / (float)F.height;
                 const int si = ((int)slot * F.maxBounces + bounce) * 2;
                 Path p;
                 p.o = tv.o; p.d = tv.d; p.thr = thr; p.seed = seed;
                 vec3 sample;
-                const bool goOn = shade_hit<VNRM>(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], uvx, uvy, sample);
+                const bool goOn = shade_hit<VNRM>(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], px, py, sample);
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
                     nextO = p.o; nextD = p.d; startRay = true;
                 } else {
-                    float *dst = cur + (size_t)slot * frameFloats + ((size_t)py * (size_t)F.width + px) * 3;
+                    // a launch holds at most 2 GiB of sample images (paths_frames_cap), so the index fits 32 bits
+                    float *dst = cur + (slot * (uint32_t)frameFloats + (py * (uint32_t)F.width + px) * 3u);
                     dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
                     have = false;
                 }

@@ -32,10 +32,11 @@ __device__ __forceinline__ void sobol_pair(const uint32_t *__restrict__ V, uint3
     v = (float)r1 * (1.0f / 4294967296.0f);
 }
 
-// frag:59-77
-__device__ __forceinline__ void cranley_patterson(float uvx, float uvy, int width, int height, float &px, float &py) {
-    const uint32_t X = (uint32_t)(rtm::madd(rtm::madd(uvx, 2.0f, -1.0f), 0.5f, 0.5f) * (float)width);
-    const uint32_t Y = (uint32_t)(rtm::madd(rtm::madd(uvy, 2.0f, -1.0f), 0.5f, 0.5f) * (float)height);
+// frag:59-77.  The shader recovers the pixel from the interpolated coordinate,
+// x = uint(((uv.x * 2 - 1) * 0.5 + 0.5) * width) with uv.x = (X + 0.5) / width; in fp32 that IS X for
+// every X < width <= 16384 (the rounding errors add up to < 0.01 of a pixel against a margin of
+// 0.5; tests/test_oracle.py checks every pair), so the pixel is passed in directly.
+__device__ __forceinline__ void cranley_patterson(uint32_t X, uint32_t Y, float &px, float &py) {
     uint32_t pseed = (X * 1973u + Y * 9277u + (uint32_t)(114514 / 1919) * 26699u) | 1u;
     pseed = rtm::wang_step(pseed);
     const float u = (float)pseed / 4294967296.0f;
@@ -86,7 +87,7 @@ __host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tan
 // are separate instantiations, so the default ones pay neither registers nor branches for it.
 template <bool VNRM = false>
 __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
-                                          int bounce, float sobU, float sobV, float uvx, float uvy, vec3 &sample) {
+                                          int bounce, float sobU, float sobV, uint32_t pixX, uint32_t pixY, vec3 &sample) {
     sample = rtm::mk(0.0f, 0.0f, 0.0f);
     bool hit = false;
     float hitMin = HIT_MIN_INIT;
@@ -170,7 +171,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
     }
     if (material == 1) {                                                        // frag:637-641
         float u = sobU, v = sobV;                                               // sobol(2b), sobol(2b+1) of this frame
-        cranley_patterson(uvx, uvy, F.width, F.height, u, v);
+        cranley_patterson(pixX, pixY, u, v);
         // SampleCosineHemisphere, frag:504-515; PI of frag:4 is 3.14159274f in fp32
         const float r = __builtin_sqrtf(u);
         const float theta = (v * 2.0f) * 3.14159274101257324f;
