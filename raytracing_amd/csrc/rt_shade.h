@@ -89,56 +89,56 @@ template <bool VNRM = false>
 __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
                                           int bounce, float sobU, float sobV, uint32_t pixX, uint32_t pixY, vec3 &sample) {
     sample = rtm::mk(0.0f, 0.0f, 0.0f);
-    bool hit = false;
-    float hitMin = HIT_MIN_INIT;
-    vec3 pos = rtm::mk(0, 0, 0), nrm = rtm::mk(0, 0, 0), albedo = rtm::mk(0, 0, 0);
-    int material = -1;
-    float refraction = 1.0f;
+    // The triangle part runs for every lane (a lane without a triangle reads record 0 and drops the
+    // result): no lane-dependent branch, and every value below is defined on one path only.
+    const bool triHit = tri != REF_NONE;
+    const float4 *m = S.mats + (size_t)(triHit ? tri : 0u) * 5;
+    const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4];
+    vec3 pos = rtm::along(p.o, tTri, p.d);                                      // frag:458
+    vec3 nrm = rtm::mk(m2.y, m2.z, m2.w);                                       // frag:296-300, precomputed
     // tangent frame of the hit: taken from the triangle's record, computed for a sphere
-    bool recFrame = false;
-    vec3 tangent = rtm::mk(0, 0, 0), bitangent = rtm::mk(0, 0, 0);
-    if (tri != REF_NONE) {
-        const float4 *m = S.mats + (size_t)tri * 5;
-        const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4];
-        pos = rtm::along(p.o, tTri, p.d);                                       // frag:458
-        nrm = rtm::mk(m2.y, m2.z, m2.w);                                        // frag:296-300, precomputed
-        tangent = rtm::mk(m3.x, m3.y, m3.z);
-        bitangent = rtm::mk(m3.w, m4.x, m4.y);
-        recFrame = true;
-        if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
-        if constexpr (VNRM) {
-            // RtOptions.shading_normals: vertex normals interpolated with the edge functions of
-            // hitTriangle (frag:265-275) at the hit position, normalised, turned to the side of
-            // the face normal; a zero, infinite or NaN sum keeps the face normal
-            const float4 *g = S.tris + (size_t)tri * 4;
-            const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-            const float4 *vn = S.vnrm + (size_t)tri * 3;
-            const float4 a0 = vn[0], a1 = vn[1], a2 = vn[2];
-            const vec3 v0 = rtm::mk(g0.x, g0.y, g0.z), v1 = rtm::mk(g0.w, g1.x, g1.y), v2 = rtm::mk(g1.z, g1.w, g2.x);
-            const vec3 N = rtm::mk(g2.y, g2.z, g2.w);
-            const float w2 = rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pos, v0)));
-            const float w0 = rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pos, v1)));
-            const float w1 = rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pos, v2)));
-            vec3 n = rtm::mk(rtm::madd(w2, a1.z, rtm::madd(w1, a0.w, w0 * a0.x)),
-                             rtm::madd(w2, a1.w, rtm::madd(w1, a1.x, w0 * a0.y)),
-                             rtm::madd(w2, a2.x, rtm::madd(w1, a1.y, w0 * a0.z)));
-            const float l2 = rtm::dot(n, n);
-            if ((l2 > 0.0f) && (l2 < INFINITY)) {
-                n = rtm::scale(n, rtm::rsqrt_exact(l2));
-                if (rtm::dot(n, nrm) < 0.0f) n = rtm::neg(n);
-                nrm = n;
-                recFrame = false;
-            }
+    vec3 tangent = rtm::mk(m3.x, m3.y, m3.z);
+    vec3 bitangent = rtm::mk(m3.w, m4.x, m4.y);
+    bool recFrame = true;
+    if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
+    if constexpr (VNRM) if (triHit) {
+        // RtOptions.shading_normals: vertex normals interpolated with the edge functions of
+        // hitTriangle (frag:265-275) at the hit position, normalised, turned to the side of
+        // the face normal; a zero, infinite or NaN sum keeps the face normal
+        const float4 *g = S.tris + (size_t)tri * 4;
+        const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+        const float4 *vn = S.vnrm + (size_t)tri * 3;
+        const float4 a0 = vn[0], a1 = vn[1], a2 = vn[2];
+        const vec3 v0 = rtm::mk(g0.x, g0.y, g0.z), v1 = rtm::mk(g0.w, g1.x, g1.y), v2 = rtm::mk(g1.z, g1.w, g2.x);
+        const vec3 N = rtm::mk(g2.y, g2.z, g2.w);
+        const float w2 = rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pos, v0)));
+        const float w0 = rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pos, v1)));
+        const float w1 = rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pos, v2)));
+        vec3 n = rtm::mk(rtm::madd(w2, a1.z, rtm::madd(w1, a0.w, w0 * a0.x)),
+                         rtm::madd(w2, a1.w, rtm::madd(w1, a1.x, w0 * a0.y)),
+                         rtm::madd(w2, a2.x, rtm::madd(w1, a1.y, w0 * a0.z)));
+        const float l2 = rtm::dot(n, n);
+        if ((l2 > 0.0f) && (l2 < INFINITY)) {
+            n = rtm::scale(n, rtm::rsqrt_exact(l2));
+            if (rtm::dot(n, nrm) < 0.0f) n = rtm::neg(n);
+            nrm = n;
+            recFrame = false;
         }
-        const float temp = rand01(p.seed);                                      // frag:462
-        const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
-        const float ksx = m1.z, ksy = m1.w;
-        if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }             // length(ka) > 0
-        else if (temp < ksx) { material = 1; albedo = kd; }
-        else if (temp < ksy) { material = 2; albedo = rtm::mk(1.0f, 1.0f, 1.0f); }
-        else { material = 3; albedo = rtm::mk(1.0f, 1.0f, 1.0f); refraction = 1.5f; }
-        if (tTri > 0.0f && tTri < hitMin) { hitMin = tTri; hit = true; }        // frag:562-565
     }
+    uint32_t seedT = p.seed;
+    const float tempT = rand01(seedT);                                          // frag:462
+    if (triHit) p.seed = seedT;
+    const vec3 ka = rtm::mk(m0.x, m0.y, m0.z), kd = rtm::mk(m0.w, m1.x, m1.y);
+    const float ksx = m1.z, ksy = m1.w;
+    int material;
+    vec3 albedo = rtm::mk(1.0f, 1.0f, 1.0f);
+    float refraction = 1.0f;
+    if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }                 // length(ka) > 0
+    else if (tempT < ksx) { material = 1; albedo = kd; }
+    else if (tempT < ksy) { material = 2; }
+    else { material = 3; refraction = 1.5f; }
+    bool hit = triHit && tTri > 0.0f && tTri < HIT_MIN_INIT;                    // frag:562-565
+    float hitMin = hit ? tTri : HIT_MIN_INIT;
     for (int i = 0; i < F.sphereNum; i++) {                                     // frag:570-614
         const RtSphere &s = F.sph[i];
         const float dis = sphere_test(s, p.o, p.d);
