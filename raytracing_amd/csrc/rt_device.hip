@@ -924,7 +924,7 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
             std::memcpy(&o[3], w, 16);
         }
     });
-    hTris.resize((size_t)n * 4); hMats.resize((size_t)n * 5);
+    hTris.resize((size_t)n * TRI_RECORD); hMats.resize((size_t)n * 5);
     parallel_for(n, [&](int64_t ib, int64_t ie) {
     for (int64_t i = ib; i < ie; i++) {
         const RtTriangle &t = tris[i];
@@ -932,11 +932,9 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
         const vec3 v1 = rtm::mk(t.v[1][0], t.v[1][1], t.v[1][2]);
         const vec3 v2 = rtm::mk(t.v[2][0], t.v[2][1], t.v[2][2]);
         const vec3 N = rtm::normalize(rtm::cross(rtm::sub(v1, v0), rtm::sub(v2, v0)));      // frag:257-259
-        const float D = -rtm::dot(N, v0);                                                  // frag:262
-        hTris[(size_t)i * 4 + 0] = make_float4(v0.x, v0.y, v0.z, v1.x);
-        hTris[(size_t)i * 4 + 1] = make_float4(v1.y, v1.z, v2.x, v2.y);
-        hTris[(size_t)i * 4 + 2] = make_float4(v2.z, N.x, N.y, N.z);
-        hTris[(size_t)i * 4 + 3] = make_float4(D, 0.0f, 0.0f, 0.0f);
+        hTris[(size_t)i * TRI_RECORD + 0] = make_float4(v0.x, v0.y, v0.z, v1.x);
+        hTris[(size_t)i * TRI_RECORD + 1] = make_float4(v1.y, v1.z, v2.x, v2.y);
+        hTris[(size_t)i * TRI_RECORD + 2] = make_float4(v2.z, N.x, N.y, N.z);
         // shading record: materials, the shading normal of getTriangleNormal (frag:296-300; the
         // operand order differs from N above) and its tangent frame (frag:494-500)
         const vec3 nS = rtm::normalize(rtm::cross(rtm::sub(v2, v0), rtm::sub(v1, v0)));

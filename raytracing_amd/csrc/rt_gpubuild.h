@@ -17,7 +17,7 @@ struct GpuIndex {
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
 };
 
-// dTris: the device triangle records (4 x float4 each, vertices in the first nine floats).
+// dTris: the device triangle records (3 x float4 each, vertices in the first nine floats).
 // sceneMin/sceneMax: box of all vertices (normalises the Morton codes); sceneMaxAbs: its largest
 // |coordinate| (sizes the growth of the boxes, as in build_accel).  Synchronises `st`.
 int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], const float sceneMax[3], float sceneMaxAbs,

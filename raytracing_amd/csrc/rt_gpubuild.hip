@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BLOCK) void k_prims(const float4 *__restrict__ tris
                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ ids) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const float4 q0 = tris[(size_t)i * 4], q1 = tris[(size_t)i * 4 + 1], q2 = tris[(size_t)i * 4 + 2];
+    const float4 q0 = tris[(size_t)i * 3], q1 = tris[(size_t)i * 3 + 1], q2 = tris[(size_t)i * 3 + 2];
     const float v[3][3] = {{q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}};
     double A[3], B[3];
     for (int k = 0; k < 3; k++) { A[k] = (double)v[1][k] - v[0][k]; B[k] = (double)v[2][k] - v[0][k]; }

@@ -14,9 +14,9 @@
 //          both children, so one fetch decides both (the reference fetches 9 floats per child
 //          and tests a box only after descending to it).  Leaves (always one triangle,
 //          BVH.h:207-211) have no record: the parent stores LEAF|triangle index.
-//   tris:  one 64-byte record per triangle: v0 v1 v2, the unit normal N and plane offset D
-//          that hitTriangle (frag:257-262) recomputes for every ray (they depend on the
-//          triangle only, and are computed with the same arithmetic).
+//   tris:  one 48-byte record per triangle: v0 v1 v2 and the unit normal N that hitTriangle
+//          (frag:257-259) recomputes for every ray (it depends on the triangle only, and is
+//          computed with the same arithmetic).  Three 16-byte loads per test.
 //   mats:  one 80-byte record per triangle, read once per final hit: ka kd ks (frag:220-230),
 //          the shading normal (frag:296-300) and its tangent frame (frag:494-500), which depend
 //          on the triangle only.
@@ -35,6 +35,7 @@ namespace rtd {
 
 using rtm::vec3;
 
+constexpr int TRI_RECORD = 3;                  // float4 per triangle record (v0 v1 v2 N)
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;     // also "no triangle"
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builti
 
 struct SceneD {
     const float4 *nodes;    // 4 x float4 per interior node
-    const float4 *tris;     // 4 x float4 per triangle
+    const float4 *tris;     // TRI_RECORD x float4 per triangle
     const float4 *mats;     // 5 x float4 per triangle
     const float4 *vnrm;     // RtOptions.shading_normals: 3 x float4 per triangle (n0 n1 n2 | pad), else nullptr
     float rootMin[3];

@@ -105,7 +105,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
         // RtOptions.shading_normals: vertex normals interpolated with the edge functions of
         // hitTriangle (frag:265-275) at the hit position, normalised, turned to the side of
         // the face normal; a zero, infinite or NaN sum keeps the face normal
-        const float4 *g = S.tris + (size_t)tri * 4;
+        const float4 *g = S.tris + (size_t)tri * TRI_RECORD;
         const float4 g0 = g[0], g1 = g[1], g2 = g[2];
         const float4 *vn = S.vnrm + (size_t)tri * 3;
         const float4 a0 = vn[0], a1 = vn[1], a2 = vn[2];

@@ -144,7 +144,7 @@ struct Trav {
     // cur is a leaf: test its triangle, keep it if closer (frag:390-403), then pop
     __device__ __forceinline__ void leaf_step(const SceneD &S, const uint32_t *stack, const int stride, uint32_t &nTri) {
         const uint32_t ti = cur & ~LEAF_BIT;
-        const float4 *rec = S.tris + (size_t)ti * 4;
+        const float4 *rec = S.tris + (size_t)ti * TRI_RECORD;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const float dis = triangle_test(q0, q1, q2, o, d);
         if (COUNT) nTri++;
@@ -352,7 +352,7 @@ struct FastTrav {
     // tests one queued triangle with the reference's hitTriangle arithmetic
     __device__ __forceinline__ void test_step(const SceneD &S, const uint32_t *col, const int stride, uint32_t &nTri) {
         const uint32_t ti = unqueue_triangle(col, stride);
-        const float4 *rec = S.tris + (size_t)ti * 4;
+        const float4 *rec = S.tris + (size_t)ti * TRI_RECORD;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const float dis = triangle_test(q0, q1, q2, o, d);
         if (COUNT) nTri++;
@@ -376,7 +376,7 @@ struct FastTrav {
 // implies a pass at every ancestor: testing the leaf's own box (the min/max of the triangle's
 // vertices, BVH.h:42-54) is enough.
 __device__ __forceinline__ bool verify_reference_reaches(const SceneD &S, const vec3 o, const vec3 inv, uint32_t tri) {
-    const float4 *rec = S.tris + (size_t)tri * 4;
+    const float4 *rec = S.tris + (size_t)tri * TRI_RECORD;
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const float mnx = fminf(fminf(q0.x, q0.w), q1.z), mxx = fmaxf(fmaxf(q0.x, q0.w), q1.z);
     const float mny = fminf(fminf(q0.y, q1.x), q1.w), mxy = fmaxf(fmaxf(q0.y, q1.x), q1.w);
