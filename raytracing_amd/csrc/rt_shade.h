@@ -35,7 +35,7 @@ __device__ __forceinline__ void sobol_pair(const uint32_t *__restrict__ V, uint3
 // frag:59-77.  The shader recovers the pixel from the interpolated coordinate,
 // x = uint(((uv.x * 2 - 1) * 0.5 + 0.5) * width) with uv.x = (X + 0.5) / width; in fp32 that IS X for
 // every X < width <= 16384 (the rounding errors add up to < 0.01 of a pixel against a margin of
-// 0.5; tests/test_oracle.py checks every pair), so the pixel is passed in directly.
+// 0.5; tests/test_sobol.py checks every pair), so the pixel is passed in directly.
 __device__ __forceinline__ void cranley_patterson(uint32_t X, uint32_t Y, float &px, float &py) {
     uint32_t pseed = (X * 1973u + Y * 9277u + (uint32_t)(114514 / 1919) * 26699u) | 1u;
     pseed = rtm::wang_step(pseed);

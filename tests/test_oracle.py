@@ -121,17 +121,3 @@ def test_shading_normal_mode_of_the_oracle():
     t["n"] *= -1.0
     back, _ = ol.scene_from_build(t, nodes, W, H, V, sc.spheres(), shading_normals=True).render(cam, 1, ro)
     assert np.array_equal(np.nan_to_num(back), np.nan_to_num(tilted))
-
-
-def test_pixel_recovered_from_its_coordinate_is_the_pixel():
-    """frag:62-63 turns the interpolated coordinate back into a pixel index,
-    uint(((uv*2-1)*0.5+0.5)*width) with uv = (X+0.5)/width.  The library passes X itself; that is
-    the same number for every X < width <= 16384 (all widths the library accepts).  Multiplying by 2
-    and by 0.5 is exact, so the fused and unfused readings agree and numpy's fp32 reproduces both."""
-    half, one, two = np.float32(0.5), np.float32(1.0), np.float32(2.0)
-    for w in range(1, 16385):
-        x = np.arange(w, dtype=np.float32)
-        wf = np.float32(w)
-        uv = (x + half) / wf
-        back = (((uv * two - one) * half + half) * wf).astype(np.uint32)
-        assert np.array_equal(back, np.arange(w, dtype=np.uint32)), w

@@ -65,3 +65,17 @@ def test_rand_origin_stream_is_deterministic_and_in_range():
     assert np.array_equal(a, b)
     assert a.min() >= 874264.0 and a.max() < 2 * 874264.0
     assert len(np.unique(a)) > 990
+
+
+def test_pixel_recovered_from_its_coordinate_is_the_pixel():
+    """frag:62-63 turns the interpolated coordinate back into a pixel index,
+    uint(((uv*2-1)*0.5+0.5)*width) with uv = (X+0.5)/width.  The library passes X itself; that is
+    the same number for every X < width <= 16384 (all widths the library accepts).  Multiplying by 2
+    and by 0.5 is exact, so the fused and unfused readings agree and numpy's fp32 reproduces both."""
+    half, one, two = np.float32(0.5), np.float32(1.0), np.float32(2.0)
+    for w in range(1, 16385):
+        x = np.arange(w, dtype=np.float32)
+        wf = np.float32(w)
+        uv = (x + half) / wf
+        back = (((uv * two - one) * half + half) * wf).astype(np.uint32)
+        assert np.array_equal(back, np.arange(w, dtype=np.uint32)), w
