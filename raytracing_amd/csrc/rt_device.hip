@@ -28,6 +28,10 @@ using rtm::vec3;
 namespace {
 
 constexpr int BLOCK = 256;          // 4 waves
+#ifndef RT_PATHS_BLOCK
+#define RT_PATHS_BLOCK 256
+#endif
+constexpr int PATHS_BLOCK = RT_PATHS_BLOCK;     // threads per block of the persistent path kernel
 // Ray queues are split into NSHARD independent sub-queues, each with its own fill count and
 // dequeue head on its own 128-byte line: one device-scope atomic word sustains only ~90
 // operations per microsecond, and a 1080p frame needs ~32k wave-granular pushes and pops per
@@ -399,18 +403,18 @@ __global__ void k_sobol_table(const BatchD B, const int maxBounces, const uint32
 // FAST: closest hit through the search index with the proof/re-trace of k_extend_fast;
 // otherwise the reference's tree in the reference's order (Trav<CULL>).
 template <bool FAST, bool CULL, bool COUNT, int OCC, bool VNRM = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths(const SceneD S, const FrameD F, const BatchD B,
+__global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths(const SceneD S, const FrameD F, const BatchD B,
                                                  const float *__restrict__ sob, uint32_t *__restrict__ workHead, float *__restrict__ cur,
                                                  WorkCounters *__restrict__ wc) {
     extern __shared__ uint32_t lds_dyn[];
     uint32_t *stack = lds_dyn + threadIdx.x;
-    uint32_t *ovf = FAST ? S.aovf + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
+    uint32_t *ovf = FAST ? S.aovf + (size_t)blockIdx.x * PATHS_BLOCK + threadIdx.x : nullptr;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t tilesX = (uint32_t)(F.width + 7) >> 3, tilesY = (uint32_t)(F.height + 7) >> 3;
     const uint32_t framePix = tilesX * tilesY * 64u;
     const uint32_t total = framePix * (uint32_t)B.nframes;
     const size_t frameFloats = (size_t)F.width * (size_t)F.height * 3;
-    const uint32_t nWaves = gridDim.x * (BLOCK / 64);
+    const uint32_t nWaves = gridDim.x * (PATHS_BLOCK / 64);
 
     uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
 #ifdef RT_EXP_TIMELINE
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
             }
             // continued and new paths start their rays together
             if (startRay) {
-                if constexpr (FAST) tv.begin(S, stack, BLOCK, nextO, nextD, cNode); else tv.begin(S, nextO, nextD, cNode);
+                if constexpr (FAST) tv.begin(S, stack, PATHS_BLOCK, nextO, nextD, cNode); else tv.begin(S, nextO, nextD, cNode);
             }
             {   // the value is wave uniform; saying so keeps it in scalar registers across the loop
                 const unsigned long long m = ballot64(have);
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
 #ifdef RT_EXP_PROFILE
             { const unsigned long long ms = ballot64(step); if (ms) xNode += 1ull + ((unsigned long long)__popcll(ms) << 32); }
 #endif
-            if (step) tv.node_step(S, stack, BLOCK, ovf, cNode);
+            if (step) tv.node_step(S, stack, PATHS_BLOCK, ovf, cNode);
             // wants_test() and can_step() of every lane, from three compares and scalar logic
             const unsigned long long mNone = ballot64(tv.cur == REF_NONE);
             const unsigned long long mFull = ballot64(tv.npend > FastTrav<COUNT>::PEND_MAX - 4);
@@ -598,12 +602,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
 #ifdef RT_EXP_PROFILE
                 xTest += 1ull + ((unsigned long long)__popcll(ballot64(tv.npend > 0)) << 32);
 #endif
-                if (tv.npend > 0) tv.test_step(S, stack, BLOCK, cTri);
+                if (tv.npend > 0) tv.test_step(S, stack, PATHS_BLOCK, cTri);
             }
         } else {
             if (have) {
-                if (tv.at_interior()) tv.node_step(S, stack, BLOCK, cNode);
-                else if (tv.at_leaf()) tv.leaf_step(S, stack, BLOCK, cTri);
+                if (tv.at_interior()) tv.node_step(S, stack, PATHS_BLOCK, cNode);
+                else if (tv.at_leaf()) tv.leaf_step(S, stack, PATHS_BLOCK, cTri);
             }
         }
     }
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC)
         uint32_t r = cRays;
         for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
         if (lane == 0) {
-            unsigned long long *o = S.timeline + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 5;
+            unsigned long long *o = S.timeline + (size_t)(blockIdx.x * (PATHS_BLOCK / 64) + (threadIdx.x >> 6)) * 5;
             o[0] = tlStart; o[1] = wall_clock64(); o[2] = r; o[3] = tlIter; o[4] = tlExhausted;
         }
     }
@@ -1353,7 +1357,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
         const int occ = vnrm ? 5 : paths_occupancy(ctx);
-        const int blocks = ctx->numCU * (fast ? occ : 5);
+        const int blocks = ctx->numCU * (fast ? occ : 5) * (BLOCK / PATHS_BLOCK);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
         if (overlap && !ctx->inputEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->inputEvent, hipEventDisableTiming));
         for (int off = 0; off < count; off += cap) {
@@ -1388,15 +1392,15 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             SceneD Sp = S;
             Sp.leafBatch = ctx->pathsLeafBatch;
             Sp.aovf = ctx->dAOvf[si];       // concurrent launches must not share overflow columns
-            const size_t ldsP = fast ? fast_stack_bytes(ctx) : lds;
+            const size_t ldsP = (fast ? fast_stack_bytes(ctx) : lds) * PATHS_BLOCK / BLOCK;
             const int sobWords = B.nframes * F.maxBounces * 2;
             hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, ps, B, F.maxBounces, ctx->dSobolV, sl.dSobTable);
             HIP_TRY(ctx, hipMemsetAsync(sl.dWorkHead, 0, sizeof(uint32_t), ps));
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
             HIP_TRY(ctx, hipEventRecord(e0, ps));
-#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
-#define LAUNCH_PATHS_VN(A, C) hipLaunchKernelGGL((k_paths<A, C, true, 5, true>), dim3(blocks), dim3(BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
+#define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(PATHS_BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
+#define LAUNCH_PATHS_VN(A, C) hipLaunchKernelGGL((k_paths<A, C, true, 5, true>), dim3(blocks), dim3(PATHS_BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
             if (vnrm) {     // shading with vertex normals: the counting instantiations only
                 if (fast) LAUNCH_PATHS_VN(true, true); else if (cull) LAUNCH_PATHS_VN(false, true); else LAUNCH_PATHS_VN(false, false);
             }
