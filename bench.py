@@ -111,8 +111,9 @@ def main():
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="traverse the reference's tree in the reference's order")
     ap.add_argument("--resolution", default=None, help="WxH override for sensitivity runs (the named workload's resolution is the default)")
-    ap.add_argument("--gpu-index", action="store_true",
-                    help="build the search index on the GPU at upload (milliseconds instead of seconds; more boxes per ray)")
+    ap.add_argument("--gpu-index", action="store_true", help="build the search index on the GPU at upload whatever the scene size")
+    ap.add_argument("--host-index", action="store_true", help="build the search index on the host whatever the scene size "
+                    "(default: RtOptions.index_build = auto, on the GPU from a million triangles on)")
     ap.add_argument("--no-overlap", action="store_true", help="keep every launch on the context's stream (RtOptions.overlap = 0)")
     ap.add_argument("--total-spp", type=int, default=0,
                     help="strong scaling: this many frames in the whole job, split evenly over ranks and steps "
@@ -156,7 +157,7 @@ def main():
                 "persistent": rt.PIPELINE_PERSISTENT}[args.pipeline]
 
     opts = dict(max_bounces=bounces, pipeline=pipeline, cull=not args.no_cull, accel=not args.no_accel,
-                overlap=not args.no_overlap, index_build=rt.INDEX_BUILD_GPU if args.gpu_index else rt.INDEX_BUILD_HOST)
+                overlap=not args.no_overlap, index_build=rt.INDEX_BUILD_GPU if args.gpu_index else (rt.INDEX_BUILD_HOST if args.host_index else rt.INDEX_BUILD_AUTO))
     r = rt.Renderer(W, H, local_rank)
     r.set_options(count_work=False, **opts)
     t_up = time.time()
@@ -276,7 +277,7 @@ def main():
                        "pipeline": args.pipeline, "cull": not args.no_cull, "search_index": not args.no_accel,
                        "parallelism": f"spp-partition x{world}, one RCCL sum-reduce" if world > 1 else "single GPU",
                        "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
-                       "scene_upload_s": round(upload_s, 3), "index_build": "gpu" if args.gpu_index else "host",
+                       "scene_upload_s": round(upload_s, 3), "index_build": "gpu" if info["index_built_on_device"] else "host",
                        "overlap": not args.no_overlap,
                        "image_mean": float(mean_img.mean())},
             # The scene (index + triangles) is served by L1 / L2 / Infinity Cache, so the roof that

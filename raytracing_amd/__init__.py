@@ -28,6 +28,7 @@ PIPELINE_MEGAKERNEL = 1
 PIPELINE_PERSISTENT = 2
 INDEX_BUILD_HOST = 0
 INDEX_BUILD_GPU = 1
+INDEX_BUILD_AUTO = 2        # default: on the device from a million triangles on, on the host below
 
 # numpy views of the C structs of include/rt_amd.h
 TRIANGLE_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("n", "<f4", (3, 3)), ("tex", "<f4", (3, 2)),
@@ -60,7 +61,8 @@ class RtCameraRig(C.Structure):
 class RtSceneInfo(C.Structure):
     _fields_ = [("triangles", C.c_int64), ("index_nodes", C.c_int64), ("tree_height", C.c_int32),
                 ("index_stack_need", C.c_int32), ("index_stack_lds", C.c_int32), ("index_enabled", C.c_int32),
-                ("paths_waves_per_simd", C.c_int32), ("frames_per_launch", C.c_int32)]
+                ("paths_waves_per_simd", C.c_int32), ("frames_per_launch", C.c_int32),
+                ("index_built_on_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RtOptions(C.Structure):
@@ -309,7 +311,7 @@ class Renderer:
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
     def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True,
-                    history8=False, overlap=True, index_build=0, shading_normals=False):
+                    history8=False, overlap=True, index_build=2, shading_normals=False):
         o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8), int(overlap), int(index_build),
                       int(shading_normals))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)

@@ -726,6 +726,7 @@ struct RtContext {
     bool boxesExact = true;         // the uploaded boxes are the nested min/max boxes the proof step needs
     SceneD scene{};
     bool haveScene = false;
+    bool indexOnDevice = false;
 
     FrameD frame{};
     bool haveCamera = false;
@@ -1005,7 +1006,7 @@ int rt_default_options(RtOptions *out) {
     out->accel = 1;
     out->history8 = 0;
     out->overlap = 1;
-    out->index_build = RT_INDEX_BUILD_HOST;
+    out->index_build = RT_INDEX_BUILD_AUTO;
     out->shading_normals = 0;
     return RT_OK;
 }
@@ -1112,7 +1113,7 @@ int rt_set_options(RtContext *ctx, const RtOptions *opt) {
     if (!ctx || !opt) return fail(ctx, RT_E_INVALID, "rt_set_options: null pointer");
     if (opt->max_bounces < 1 || opt->max_bounces > RT_MAX_BOUNCES) return fail(ctx, RT_E_INVALID, "rt_set_options: max_bounces must be in 1..8");
     if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL && opt->pipeline != RT_PIPELINE_PERSISTENT) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
-    if (opt->index_build != RT_INDEX_BUILD_HOST && opt->index_build != RT_INDEX_BUILD_GPU) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown index_build");
+    if (opt->index_build != RT_INDEX_BUILD_HOST && opt->index_build != RT_INDEX_BUILD_GPU && opt->index_build != RT_INDEX_BUILD_AUTO) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown index_build");
     if (opt->shading_normals != 0 && ctx->haveScene && !ctx->dVNrm)
         return fail(ctx, RT_E_STATE, "rt_set_options: shading_normals needs a scene uploaded with the option already set");
     ctx->opt = *opt;
@@ -1133,7 +1134,8 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     rt::Accel accel;
     bool haveAccel = false;
     const bool wantIndex = boxesExact && !getenv("RT_AMD_NO_ACCEL");
-    const bool gpuBuild = wantIndex && ctx->opt.index_build == RT_INDEX_BUILD_GPU;
+    const bool gpuBuild = wantIndex && (ctx->opt.index_build == RT_INDEX_BUILD_GPU ||
+                                        (ctx->opt.index_build == RT_INDEX_BUILD_AUTO && n >= RT_INDEX_AUTO_GPU_TRIANGLES));
     if (wantIndex && !gpuBuild) {
         const float maxAbs = S.cullEps * 1024.0f;
         if (rt::build_accel(tris, n, maxAbs, 1, accel) == RT_OK && accel.directLeaves && accel.wideStack <= 160) {
@@ -1225,6 +1227,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         fprintf(stderr, "rt_amd: upload of %lld triangles: host conversion %.1f ms, index + copies %.1f ms\n", (long long)n,
                 tConverted - tStart, now_ms() - tConverted);
     ctx->nIndexNodes = haveAccel ? (int64_t)indexNodes : 0;
+    ctx->indexOnDevice = haveAccel && gpuBuild;
     ctx->indexStackNeed = haveAccel ? indexStackNeed : 0;
     return RT_OK;
 }
@@ -1544,6 +1547,7 @@ int rt_get_scene_info(RtContext *ctx, RtSceneInfo *out) {
     out->index_enabled = ctx->scene.anodes != nullptr;
     out->paths_waves_per_simd = (ctx->opt.accel != 0 && ctx->scene.anodes) ? paths_occupancy(ctx) : 5;
     out->frames_per_launch = paths_frames_cap(ctx);
+    out->index_built_on_device = ctx->indexOnDevice ? 1 : 0;
     return RT_OK;
 }
 

@@ -77,7 +77,14 @@ __global__ __launch_bounds__(BLOCK) void k_prims(const float4 *__restrict__ tris
         const uint32_t u = (uint32_t)(t * 2097151.0f);
         q[k] = u > 2097151u ? 2097151u : u;
     }
-    keys[i] = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+    // Two leading bits order the triangles by size class first (a quarter, a sixteenth, a sixty-fourth
+    // of the scene's extent, smaller): a few large triangles in Morton order among small ones - the
+    // walls of a room around a dense mesh - would give every node above them a room-sized box; this
+    // way they get subtrees of their own below the root.
+    float frac = 0.0f;
+    for (int k = 0; k < 3; k++) frac = fmaxf(frac, (b.mx[k] - b.mn[k]) * inv[k]);
+    const uint64_t cls = (frac >= 0.25f) ? 0ull : ((frac >= 0.0625f) ? 1ull : ((frac >= 0.015625f) ? 2ull : 3ull));
+    keys[i] = cls << 62 | (spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2])) >> 1;
     ids[i] = i;
 }
 
@@ -283,9 +290,9 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
         out.rootRef = LEAF | 0u; out.wideDepth = 0; out.wideCount = 0; out.wide = nullptr;
         goto done;
     }
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 63, st));
+    GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 64, st));
     GB_TRY(hipMalloc(&tmp, std::max<size_t>(tmpBytes, 16)));
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 63, st));
+    GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 64, st));
     GB_TRY(hipMalloc(&left, nInt * 4)); GB_TRY(hipMalloc(&right, nInt * 4));
     GB_TRY(hipMalloc(&parI, nInt * 4)); GB_TRY(hipMalloc(&parL, (size_t)N * 4));
     GB_TRY(hipMalloc(&arrivals, nInt * 4));

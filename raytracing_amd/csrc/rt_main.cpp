@@ -3,7 +3,7 @@
 //   rt_render [--demo | --obj FILE SX SY SZ TX TY TZ ... | --synthetic KIND LEVEL COPIES]
 //             [--sphere CX CY CZ R AR AG AB DIFFUSE_RATE MIRROR_RATE] [--size W H] [--spp N]
 //             [--bounces B] [--seed S] [--camera PX PY PZ YAW PITCH FOV] [--exact] [--megakernel | --wavefront] [--history8]
-//             [--shading-normals] [--gpu-index]
+//             [--shading-normals] [--gpu-index | --host-index]
 //             [--out image.pfm] [--ppm image.ppm]
 //
 // Loads the scene (Model + Scene::pushModel), builds the BVH in the reference's node order
@@ -30,7 +30,7 @@ static int die(const char *what, RtContext *ctx) {
 int main(int argc, char **argv) {
     int W = 1200, H = 800, spp = 16, bounces = 4;     // SCR_WIDTH/SCR_HEIGHT of main.cpp:29-30
     uint32_t seed = 20221003u;
-    bool exact = false, mega = false, wavefront = false, history8 = false, shadingNormals = false, gpuIndex = false, customCam = false, haveGeometry = false;
+    bool exact = false, mega = false, wavefront = false, history8 = false, shadingNormals = false, gpuIndex = false, hostIndex = false, customCam = false, haveGeometry = false;
     float camArgs[6] = {0, 2, 5, -90, 0, 45};
     std::string outPfm, outPpm;
     RtScene *scene = nullptr;
@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
         else if (a == "--history8") history8 = true;
         else if (a == "--shading-normals") shadingNormals = true;     // interpolated vertex normals (not in the reference)
         else if (a == "--gpu-index") gpuIndex = true;                 // search index built on the device
+        else if (a == "--host-index") hostIndex = true;               // ... on the host (default: by scene size)
         else if (a == "--out") { need(1); outPfm = argv[++i]; }
         else if (a == "--ppm") { need(1); outPpm = argv[++i]; }
         else { std::fprintf(stderr, "rt_render: unknown option %s\n", a.c_str()); return 2; }
@@ -95,7 +96,7 @@ int main(int argc, char **argv) {
     opt.accel = exact ? 0 : 1;
     opt.history8 = history8 ? 1 : 0;      // the reference keeps its running mean in an 8-bit texture (RT_Screen.h:61)
     opt.shading_normals = shadingNormals ? 1 : 0;
-    opt.index_build = gpuIndex ? RT_INDEX_BUILD_GPU : RT_INDEX_BUILD_HOST;
+    opt.index_build = gpuIndex ? RT_INDEX_BUILD_GPU : (hostIndex ? RT_INDEX_BUILD_HOST : RT_INDEX_BUILD_AUTO);
     opt.pipeline = mega ? RT_PIPELINE_MEGAKERNEL : (wavefront ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_PERSISTENT);
     // before the upload: index_build and shading_normals are read there
     if (rt_set_options(ctx, &opt) != RT_OK) return die("rt_set_options", ctx);

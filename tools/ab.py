@@ -17,6 +17,11 @@ WORK = {
     "demo": ["--demo", "--frames", "64", "--warmup", "8"],
     "sponza": ["--kind", "1", "--level", "64", "--width", "3840", "--height", "2160", "--frames", "21", "--warmup", "4"],
     "stress10m": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "8"],
+    "dragon1m_hi": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "8", "--host-index"],
+    "stress10m_hi": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "8", "--host-index"],
+    "dragon1m_gi": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "8", "--gpu-index"],
+    "sponza_gi": ["--kind", "1", "--level", "64", "--width", "3840", "--height", "2160", "--frames", "21", "--warmup", "4", "--gpu-index"],
+    "stress10m_gi": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "8", "--gpu-index"],
     "dragon1m_f8": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "32", "--per-call", "8"],
     "dragon1m_f1": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "32", "--warmup", "8", "--per-call", "1"],
 }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--gpu-index", action="store_true", help="build the search index on the GPU (RtOptions.index_build)")
+    ap.add_argument("--host-index", action="store_true", help="build the search index on the host (default: auto)")
     ap.add_argument("--checksum", action="store_true", help="print a hash of the resulting mean image")
     ap.add_argument("--per-call", type=int, default=0, help="frames per rt_render_frames call (default: all at once)")
     a = ap.parse_args()
@@ -37,7 +38,7 @@ def main():
     tris, nodes = rt.bvh_build(sc.triangles())
     r = rt.Renderer(a.width, a.height, 0)
     r.set_options(max_bounces=a.bounces, pipeline=a.pipeline, cull=not a.no_cull, count_work=a.count,
-                  index_build=rt.INDEX_BUILD_GPU if a.gpu_index else rt.INDEX_BUILD_HOST)
+                  index_build=rt.INDEX_BUILD_GPU if a.gpu_index else (rt.INDEX_BUILD_HOST if a.host_index else rt.INDEX_BUILD_AUTO))
     t_up = time.perf_counter()
     r.upload(tris, nodes)
     r.synchronize()
