@@ -1134,9 +1134,9 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     rt::Accel accel;
     bool haveAccel = false;
     const bool wantIndex = boxesExact && !getenv("RT_AMD_NO_ACCEL");
-    const bool gpuBuild = wantIndex && (ctx->opt.index_build == RT_INDEX_BUILD_GPU ||
-                                        (ctx->opt.index_build == RT_INDEX_BUILD_AUTO && n >= RT_INDEX_AUTO_GPU_TRIANGLES));
-    if (wantIndex && !gpuBuild) {
+    bool gpuBuild = wantIndex && (ctx->opt.index_build == RT_INDEX_BUILD_GPU ||
+                                  (ctx->opt.index_build == RT_INDEX_BUILD_AUTO && n >= RT_INDEX_AUTO_GPU_TRIANGLES));
+    auto host_build = [&]() {
         const float maxAbs = S.cullEps * 1024.0f;
         if (rt::build_accel(tris, n, maxAbs, 1, accel) == RT_OK && accel.directLeaves && accel.wideStack <= 160) {
             haveAccel = true;
@@ -1144,7 +1144,8 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
                 fprintf(stderr, "rt_amd: search index: %zu binary / %zu 4-wide nodes, depth %d / %d; reference tree height %d\n",
                         accel.nodes.size(), accel.wide.size(), accel.maxDepth, accel.wideDepth, S.stackEntries - 1);
         }
-    }
+    };
+    if (wantIndex && !gpuBuild) host_build();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dVNrm);
@@ -1174,6 +1175,20 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     }
     S.anodes = nullptr; S.arootRef = REF_NONE; S.aovf = nullptr; S.aovfStride = 0; S.aovfRetrace = 0; S.aldsEntries = 1;
     uint32_t indexNodes = 0; int indexStackNeed = 0;
+    rt::GpuIndex gi;
+    bool haveGpuIndex = false;
+    if (gpuBuild) {
+        std::string gerr;
+        const int grc = rt::build_index_gpu(ctx->dTris, n, S.rootMin, S.rootMax, S.cullEps * 1024.0f, ctx->stream, gi, gerr);
+        if (grc == RT_OK) haveGpuIndex = true;
+        else if (ctx->opt.index_build == RT_INDEX_BUILD_GPU) return fail(ctx, grc, "rt_scene_upload: " + gerr);
+        else {      // automatic choice: the device build did not get its working memory; build on the host instead
+            if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "rt_amd: device index build failed (%s), building on the host\n", gerr.c_str());
+            (void)hipGetLastError();
+            gpuBuild = false;
+            host_build();
+        }
+    }
     if (haveAccel) {
         const size_t ab = std::max<size_t>(accel.wide.size(), 1) * sizeof(rt::WideNode);
         HIP_TRY(ctx, hipMalloc(&ctx->dANodes, ab));
@@ -1182,10 +1197,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         for (int c = 0; c < 3; c++) { S.arootMin[c] = accel.rootMin[c]; S.arootMax[c] = accel.rootMax[c]; }
         indexNodes = (uint32_t)accel.wide.size();
         indexStackNeed = std::max(accel.wideStack, 1);
-    } else if (gpuBuild) {
-        rt::GpuIndex gi; std::string gerr;
-        const int grc = rt::build_index_gpu(ctx->dTris, n, S.rootMin, S.rootMax, S.cullEps * 1024.0f, ctx->stream, gi, gerr);
-        if (grc != RT_OK) return fail(ctx, grc, "rt_scene_upload: " + gerr);
+    } else if (haveGpuIndex) {
         if (3 * gi.wideDepth + 1 <= 160) {
             haveAccel = true;
             ctx->dANodes = (float4 *)gi.wide;
