@@ -129,6 +129,7 @@ _PROTOS = {
     "rt_get_scene_info": (_int, [_vp, C.POINTER(RtSceneInfo)]),
     "rt_selftest_nth_element": (_int, [_vp, _vp, _i64, _i64]),
     "rt_selftest_arith": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "rt_selftest_exact_math": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "rt_last_error": (C.c_char_p, [_vp]),
     "rt_version": (C.c_char_p, []),
 }
@@ -403,6 +404,12 @@ class Renderer:
         ids = np.zeros(o.shape[0], dtype=np.int32)
         _check(lib.rt_trace_rays(self._h, _ptr(o), _ptr(d), o.shape[0], _ptr(t), _ptr(ids)), self._h)
         return t, ids
+
+    def selftest_exact_math(self):
+        """Mismatches of the device's 1/x, sqrt, 1/sqrt against IEEE over all 2^32 inputs (three counts)."""
+        out = (C.c_uint64 * 3)()
+        _check(lib.rt_selftest_exact_math(self._h, out), self._h)
+        return [int(v) for v in out]
 
     def selftest_arith(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.float32)

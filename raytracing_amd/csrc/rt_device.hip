@@ -364,6 +364,26 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
     sum[i] += c;
 }
 
+// Every fp32 bit pattern through recip_exact / sqrt_exact / rsqrt_exact against the compiler's IEEE
+// division and square root: out[0..2] = number of inputs whose results differ (NaNs compare equal).
+__global__ __launch_bounds__(256) void k_selftest_exact_math(unsigned long long *__restrict__ out) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
+    // all lanes of a wave run the same number of rounds (the functions vote across the wave)
+    for (unsigned long long b = tid; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float r = rtm::recip_exact(x), rw = 1.0f / x;
+        const float q = rtm::sqrt_exact(x), qw = __builtin_sqrtf(x);
+        const float i = rtm::rsqrt_exact(x), iw = 1.0f / __builtin_sqrtf(x);
+        bad0 += !((__float_as_uint(r) == __float_as_uint(rw)) || (r != r && rw != rw));
+        bad1 += !((__float_as_uint(q) == __float_as_uint(qw)) || (q != q && qw != qw));
+        bad2 += !((__float_as_uint(i) == __float_as_uint(iw)) || (i != i && iw != iw));
+    }
+    if (bad0) atomicAdd(&out[0], bad0);
+    if (bad1) atomicAdd(&out[1], bad1);
+    if (bad2) atomicAdd(&out[2], bad2);
+}
+
 // ------------------------------------------------------------------ persistent paths
 
 struct BatchD {                     // the frames one launch of k_paths renders
@@ -1560,6 +1580,25 @@ int rt_get_scene_info(RtContext *ctx, RtSceneInfo *out) {
     out->paths_waves_per_simd = (ctx->opt.accel != 0 && ctx->scene.anodes) ? paths_occupancy(ctx) : 5;
     out->frames_per_launch = paths_frames_cap(ctx);
     out->index_built_on_device = ctx->indexOnDevice ? 1 : 0;
+    return RT_OK;
+}
+
+int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[3]) {
+    if (!ctx || !mismatches) return fail(ctx, RT_E_INVALID, "rt_selftest_exact_math: null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_exact_math, dim3(ctx->numCU * 8), dim3(256), 0, ctx->stream, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(ctx, RT_E_HIP, std::string("rt_selftest_exact_math: ") + hipGetErrorString(e));
+    for (int k = 0; k < 3; k++) mismatches[k] = h[k];
     return RT_OK;
 }
 

@@ -27,7 +27,51 @@ namespace rtm {
 struct vec3 { float x, y, z; };
 
 RT_HD float madd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// 1/x, sqrt(x) and 1/sqrt(x) as IEEE-754 defines them (the last one rounds twice).  On the device the
+// compiler expands each division or square root into 11-14 instructions that also cover
+// subnormal operands and results.  One Newton step on the hardware estimate gives the same bits
+// wherever those cases cannot arise - checked for every fp32 input (rt_selftest_exact_math,
+// tools/micro/exact_math.hip): 1/x for 2^-126 <= |x| < 2^126, sqrt(x) for 2^-102 <= x < 2^128
+// (and NaN for x < -2^-102, as IEEE).  When any lane of the wave holds an operand outside those
+// ranges, the whole wave takes the full expansion; both agree on every other lane.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_IEEE_EXPANSIONS_ONLY)
+__device__ __forceinline__ float recip_newton(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float sqrt_newton(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * y, s);
+}
+__device__ __forceinline__ bool recip_in_range(float x) {        // biased exponent 1..252
+    return (__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u < 0x7E800000u - 0x00800000u;
+}
+__device__ __forceinline__ bool sqrt_in_range(float x) {         // |x| in [2^-102, 2^128)
+    return (__float_as_uint(x) & 0x7FFFFFFFu) - 0x0C800000u < 0x7F800000u - 0x0C800000u;
+}
+__device__ __forceinline__ float recip_exact(float x) {
+    float r = recip_newton(x);
+    if (__builtin_amdgcn_ballot_w64(!recip_in_range(x)) != 0ull) r = 1.0f / x;
+    return r;
+}
+__device__ __forceinline__ float sqrt_exact(float x) {
+    float s = sqrt_newton(x);
+    if (__builtin_amdgcn_ballot_w64(!sqrt_in_range(x)) != 0ull) s = __builtin_sqrtf(x);
+    return s;
+}
+__device__ __forceinline__ float rsqrt_exact(float x) {
+    // x in the sqrt range puts sqrt(x) in [2^-51, 2^64): inside the reciprocal's range
+    float r = recip_newton(sqrt_newton(x));
+    if (__builtin_amdgcn_ballot_w64(!sqrt_in_range(x) || x < 0.0f) != 0ull) r = 1.0f / __builtin_sqrtf(x);
+    return r;
+}
+#else
+RT_HD float recip_exact(float x) { return 1.0f / x; }
+RT_HD float sqrt_exact(float x) { return __builtin_sqrtf(x); }
 RT_HD float rsqrt_exact(float x) { return 1.0f / __builtin_sqrtf(x); }
+#endif
 
 RT_HD vec3 mk(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_HD vec3 add(vec3 a, vec3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -40,6 +84,17 @@ RT_HD vec3 cross(vec3 a, vec3 b) {
     return mk(madd(a.y, b.z, -(b.y * a.z)), madd(a.z, b.x, -(b.z * a.x)), madd(a.x, b.y, -(b.x * a.y)));
 }
 RT_HD vec3 normalize(vec3 a) { return scale(a, rsqrt_exact(dot(a, a))); }
+// (1/a.x, 1/a.y, 1/a.z), IEEE; on the device one range check for the three (see recip_exact)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_IEEE_EXPANSIONS_ONLY)
+__device__ __forceinline__ vec3 recip3_exact(vec3 a) {
+    vec3 r = mk(recip_newton(a.x), recip_newton(a.y), recip_newton(a.z));
+    const bool out = !recip_in_range(a.x) || !recip_in_range(a.y) || !recip_in_range(a.z);
+    if (__builtin_amdgcn_ballot_w64(out) != 0ull) r = mk(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+    return r;
+}
+#else
+RT_HD vec3 recip3_exact(vec3 a) { return mk(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
+#endif
 // o + t*d, one fused multiply-add per component
 RT_HD vec3 along(vec3 o, float t, vec3 d) { return mk(madd(t, d.x, o.x), madd(t, d.y, o.y), madd(t, d.z, o.z)); }
 

@@ -173,12 +173,12 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
         float u = sobU, v = sobV;                                               // sobol(2b), sobol(2b+1) of this frame
         cranley_patterson(pixX, pixY, u, v);
         // SampleCosineHemisphere, frag:504-515; PI of frag:4 is 3.14159274f in fp32
-        const float r = __builtin_sqrtf(u);
+        const float r = rtm::sqrt_exact(u);
         const float theta = (v * 2.0f) * 3.14159274101257324f;
         float sn, cs;
         rtm::sincos_2pi_range(theta, sn, cs);
         const float x = r * cs, y = r * sn;
-        const float z = __builtin_sqrtf(rtm::madd(-y, y, rtm::madd(-x, x, 1.0f)));
+        const float z = rtm::sqrt_exact(rtm::madd(-y, y, rtm::madd(-x, x, 1.0f)));
         // toNormalHemisphere, frag:494-500.  For a triangle the frame depends on the triangle
         // only and comes from its record (tangent_frame below, same arithmetic; negating the
         // normal negates the tangent and leaves the bitangent, exactly).

@@ -82,7 +82,7 @@ struct Trav {
         o = o_; d = d_;
         hitMin = HIT_MIN_INIT;
         best = REF_NONE;
-        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);         // frag:376
+        inv = rtm::recip3_exact(d);                                 // frag:376
         nx = inv.x < 0.0f; ny = inv.y < 0.0f; nz = inv.z < 0.0f;    // frag:378
         ex = ey = ez = hitCull = 0.0f;
         if (CULL) {
@@ -256,7 +256,7 @@ struct FastTrav {
 
     __device__ __forceinline__ void begin(const SceneD &S, uint32_t *col, const int stride, const vec3 o_, const vec3 d_, uint32_t &nNode) {
         o = o_; d = d_;
-        inv = rtm::mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        inv = rtm::recip3_exact(d);
         hitMin = HIT_MIN_INIT;
         hitCull = rtm::madd(hitMin, 1.0001f, 1.0e-4f);
         best = REF_NONE; tie = false; sp = 0; npend = 0;

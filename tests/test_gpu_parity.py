@@ -51,6 +51,15 @@ def test_device_arithmetic_matches_host():
         assert abs(float(out[i, 3]) - np.sin(float(th[i]))) < 3e-7 and abs(float(out[i, 4]) - np.cos(float(th[i]))) < 3e-7
 
 
+def test_device_reciprocal_and_square_root_are_ieee_for_every_input():
+    """rt_math.h computes 1/x, sqrt(x) and 1/sqrt(x) with one Newton step on the hardware estimate
+    where that gives the IEEE result and with the compiler's full expansion elsewhere; the
+    oracle uses the CPU's division and sqrtf.  All 2^32 inputs, on the device."""
+    r = rt.Renderer(8, 8)
+    assert r.selftest_exact_math() == [0, 0, 0]
+    r.close()
+
+
 MODES = [dict(accel=False, cull=False), dict(accel=False, cull=True), dict(accel=True, cull=True)]
 
 
