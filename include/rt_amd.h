@@ -357,11 +357,12 @@ int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d
  * rt_selftest_exact_math: runs EVERY fp32 bit pattern through the device's 1/x, sqrt(x) and
  * 1/sqrt(x) routines (a Newton step on the hardware estimate where that is exact, the full
  * IEEE expansion elsewhere) and counts the inputs whose result differs from IEEE division /
- * square root: mismatches[0..2] must be 0. */
+ * square root, and the pixel coordinate (X + 0.5) / W of every pixel of every width up to 16384
+ * (mismatches[3]): all four counts must be 0. */
 int rt_selftest_nth_element(float *keys, int32_t *ids, int64_t n, int64_t nth);
 int rt_selftest_sort(float *keys, int32_t *ids, int64_t n);     /* the builder's sort against std::sort */
 int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out);
-int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[3]);
+int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[4]);
 
 const char *rt_last_error(const RtContext *ctx);    /* ctx may be NULL: last error of a call without a context */
 const char *rt_version(void);

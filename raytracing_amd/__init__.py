@@ -406,8 +406,9 @@ class Renderer:
         return t, ids
 
     def selftest_exact_math(self):
-        """Mismatches of the device's 1/x, sqrt, 1/sqrt against IEEE over all 2^32 inputs (three counts)."""
-        out = (C.c_uint64 * 3)()
+        """Mismatches of the device's 1/x, sqrt, 1/sqrt against IEEE over all 2^32 inputs and of the pixel
+        coordinate (X + 0.5) / W over every pixel of every width (four counts)."""
+        out = (C.c_uint64 * 4)()
         _check(lib.rt_selftest_exact_math(self._h, out), self._h)
         return [int(v) for v in out]
 

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
 }
 
 // Every fp32 bit pattern through recip_exact / sqrt_exact / rsqrt_exact against the compiler's IEEE
-// division and square root: out[0..2] = number of inputs whose results differ (NaNs compare equal).
+// division and square root: out[0..2] = number of inputs whose results differ (NaNs compare equal); out[3]: pixel_coord.
 __global__ __launch_bounds__(256) void k_selftest_exact_math(unsigned long long *__restrict__ out) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
@@ -379,6 +379,14 @@ __global__ __launch_bounds__(256) void k_selftest_exact_math(unsigned long long 
         bad1 += !((__float_as_uint(q) == __float_as_uint(qw)) || (q != q && qw != qw));
         bad2 += !((__float_as_uint(i) == __float_as_uint(iw)) || (i != i && iw != iw));
     }
+    // pixel_coord for every pixel X of every width W <= 16384
+    unsigned long long bad3 = 0;
+    for (uint32_t W = blockIdx.x + 1; W <= 16384u; W += gridDim.x)
+        for (uint32_t X = threadIdx.x; X < W; X += 256u) {
+            const float g = rtm::pixel_coord(X, (float)W), w = ((float)X + 0.5f) / (float)W;
+            bad3 += __float_as_uint(g) != __float_as_uint(w);
+        }
+    if (bad3) atomicAdd(&out[3], bad3);
     if (bad0) atomicAdd(&out[0], bad0);
     if (bad1) atomicAdd(&out[1], bad1);
     if (bad2) atomicAdd(&out[2], bad2);
@@ -1583,22 +1591,22 @@ int rt_get_scene_info(RtContext *ctx, RtSceneInfo *out) {
     return RT_OK;
 }
 
-int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[3]) {
+int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[4]) {
     if (!ctx || !mismatches) return fail(ctx, RT_E_INVALID, "rt_selftest_exact_math: null pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long *d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, 3 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    HIP_TRY(ctx, hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_selftest_exact_math, dim3(ctx->numCU * 8), dim3(256), 0, ctx->stream, d);
         e = hipGetLastError();
     }
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[4] = {0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(d);
     if (e != hipSuccess) return fail(ctx, RT_E_HIP, std::string("rt_selftest_exact_math: ") + hipGetErrorString(e));
-    for (int k = 0; k < 3; k++) mismatches[k] = h[k];
+    for (int k = 0; k < 4; k++) mismatches[k] = h[k];
     return RT_OK;
 }
 

@@ -84,6 +84,17 @@ RT_HD vec3 cross(vec3 a, vec3 b) {
     return mk(madd(a.y, b.z, -(b.y * a.z)), madd(a.z, b.x, -(b.z * a.x)), madd(a.x, b.y, -(b.x * a.y)));
 }
 RT_HD vec3 normalize(vec3 a) { return scale(a, rsqrt_exact(dot(a, a))); }
+// (X + 0.5) / W, the coordinate of pixel X of W (frag:680 gets it interpolated).  On the device: the
+// refined reciprocal of W and one residual correction, the IEEE quotient for every X < W <= 16384
+// (all pairs checked by rt_selftest_exact_math and tools/micro/exact_div_uniform.hip).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_IEEE_EXPANSIONS_ONLY)
+__device__ __forceinline__ float pixel_coord(uint32_t X, float w) {
+    const float r = recip_newton(w), a = (float)X + 0.5f, q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-w, q, a), r, q);
+}
+#else
+RT_HD float pixel_coord(uint32_t X, float w) { return ((float)X + 0.5f) / w; }
+#endif
 // (1/a.x, 1/a.y, 1/a.z), IEEE; on the device one range check for the three (see recip_exact)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_IEEE_EXPANSIONS_ONLY)
 __device__ __forceinline__ vec3 recip3_exact(vec3 a) {

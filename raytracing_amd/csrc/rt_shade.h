@@ -208,8 +208,8 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
 // frag:677-689: seed and camera ray of pixel (px,py)
 __device__ __forceinline__ void generate_path(const FrameD &F, float randOrigin, uint32_t px, uint32_t py,
                                               Path &p, float &uvx, float &uvy) {
-    uvx = ((float)px + 0.5f) / (float)F.width;
-    uvy = ((float)py + 0.5f) / (float)F.height;
+    uvx = rtm::pixel_coord(px, (float)F.width);
+    uvy = rtm::pixel_coord(py, (float)F.height);
     p.seed = (uint32_t)((randOrigin * 6.95857f) * (uvx * uvy));
     p.o = rtm::mk(F.cam.camPos[0], F.cam.camPos[1], F.cam.camPos[2]);
     const float sx = (uvx * 2.0f) * F.cam.halfW;

@@ -54,9 +54,10 @@ def test_device_arithmetic_matches_host():
 def test_device_reciprocal_and_square_root_are_ieee_for_every_input():
     """rt_math.h computes 1/x, sqrt(x) and 1/sqrt(x) with one Newton step on the hardware estimate
     where that gives the IEEE result and with the compiler's full expansion elsewhere; the
-    oracle uses the CPU's division and sqrtf.  All 2^32 inputs, on the device."""
+    oracle uses the CPU's division and sqrtf.  All 2^32 inputs, on the device; likewise the pixel
+    coordinate (X + 0.5) / W for every pixel of every width up to 16384."""
     r = rt.Renderer(8, 8)
-    assert r.selftest_exact_math() == [0, 0, 0]
+    assert r.selftest_exact_math() == [0, 0, 0, 0]
     r.close()
 
 
