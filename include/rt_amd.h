@@ -132,12 +132,12 @@ typedef struct RtOptions {
                                is an input of the rendering).  0: everything runs on the context's stream. */
     int32_t index_build;    /* where rt_scene_upload builds the search index of `accel` (read at upload):
                                RT_INDEX_BUILD_HOST: binned SAH on the host (0.5 s for 1.3M triangles, 4.3 s
-                               for 10.5M); RT_INDEX_BUILD_GPU: Morton-order tree with size classes built on
-                               the device (0.1 s / 0.65 s including the upload); RT_INDEX_BUILD_AUTO
-                               (default): on the device from RT_INDEX_AUTO_GPU_TRIANGLES triangles on, where
-                               it measured as good as the host build or better, on the host below (the
-                               host build was 10 % faster to trace on a 262k-triangle interior).  Same
-                               images whichever builds it. */
+                               for 10.5M), the index that traces fastest (by 5 % on those two scenes, by
+                               12 % on a 262k-triangle interior); RT_INDEX_BUILD_GPU: Morton-order tree
+                               with size classes built on the device (0.1 s / 0.65 s including the
+                               upload); RT_INDEX_BUILD_AUTO (default): on the host below
+                               RT_INDEX_AUTO_GPU_TRIANGLES triangles, on the device from there on, where
+                               the host build takes seconds.  Same images whichever builds it. */
     int32_t shading_normals; /* 0 (default): the reference's behaviour, the face normal of getTriangleNormal
                                (frag:296-300).  1: an extension the reference only prepares - its Triangle
                                carries n0 n1 n2 (frag:131, Model.h:101-112) and the comment on
@@ -151,7 +151,7 @@ typedef struct RtOptions {
 #define RT_INDEX_BUILD_HOST 0
 #define RT_INDEX_BUILD_GPU 1
 #define RT_INDEX_BUILD_AUTO 2
-#define RT_INDEX_AUTO_GPU_TRIANGLES 1000000
+#define RT_INDEX_AUTO_GPU_TRIANGLES 4000000
 #define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
 #define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */
 #define RT_PIPELINE_PERSISTENT 2  /* persistent waves; each lane runs whole paths and takes the next (frame, pixel)

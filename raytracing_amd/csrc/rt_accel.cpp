@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -67,6 +68,31 @@ struct Builder {
         Box b; b.reset();
         for (int64_t i = begin; i < end; i++) b.grow(prims[idx[i]].mn, prims[idx[i]].mx);
         return b;
+    }
+
+    // Triangles much larger than the rest (the walls of a room around a dense mesh) are split off
+    // first, by size class: a split along an axis cannot tell an enclosing triangle from the ones
+    // it encloses, and every subtree that keeps one gets a box as large as the room.  The classes
+    // are a quarter, a sixteenth and a sixty-fourth of the scene's largest extent; a class is only
+    // split off while it is the small part (at most a tenth of the range).
+    uint32_t build_by_size(int64_t begin, int64_t end, Box &box, float sceneExtent, int cls) {
+        const int64_t count = end - begin;
+        if (cls >= 3 || count < 64) return build(begin, end, box, 3);
+        const float thr = sceneExtent * (cls == 0 ? 0.25f : (cls == 1 ? 0.0625f : 0.015625f));
+        uint32_t *first = idx + begin, *last = idx + end;
+        uint32_t *m = std::partition(first, last, [&](uint32_t id) {
+            const Prim &p = prims[id];
+            return std::max(p.mx[0] - p.mn[0], std::max(p.mx[1] - p.mn[1], p.mx[2] - p.mn[2])) >= thr;
+        });
+        const int64_t nLarge = m - first;
+        if (nLarge == 0 || nLarge * 10 > count) return build_by_size(begin, end, box, sceneExtent, cls + 1);
+        const uint32_t me = next.fetch_add(1);
+        TmpNode nd;
+        nd.left = build(begin, begin + nLarge, nd.lbox, 0);
+        nd.right = build_by_size(begin + nLarge, end, nd.rbox, sceneExtent, cls + 1);
+        nodes[me] = nd;
+        box = nd.lbox; box.grow(nd.rbox);
+        return me;
     }
 
     // Returns the ref of the subtree over idx[begin,end) and its box.
@@ -240,7 +266,14 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMa
     b.prims = prims.data(); b.idx = out.triIdx.data();
     b.nodes.resize((size_t)std::max<int64_t>(n - 1, 1));
     Box rootBox;
-    const uint32_t root = b.build(0, n, rootBox, 3);
+    uint32_t root;
+    if (getenv("RT_AMD_NO_SIZE_CLASSES")) {
+        root = b.build(0, n, rootBox, 3);
+    } else {
+        Box all = b.bounds(0, n);
+        const float ext = std::max(all.mx[0] - all.mn[0], std::max(all.mx[1] - all.mn[1], all.mx[2] - all.mn[2]));
+        root = b.build_by_size(0, n, rootBox, ext, 0);
+    }
     for (int k = 0; k < 3; k++) { out.rootMin[k] = rootBox.mn[k]; out.rootMax[k] = rootBox.mx[k]; }
     const uint32_t used = b.next.load();
     // Relayout in depth-first order (a left child follows its parent) and measure the depth.

@@ -49,12 +49,12 @@ def _rays_for(tris, seed, n=50000):
     return o, d
 
 
-@pytest.mark.parametrize("name,index", [("dragon1m", "auto"), ("dragon1m", "host"), ("sponza", "auto"),
+@pytest.mark.parametrize("name,index", [("dragon1m", "auto"), ("dragon1m", "gpu"), ("sponza", "auto"),
                                         ("stress10m", "auto"), ("stress10m", "host"), ("stress3m9", "auto")])
 def test_benchmark_workload_at_full_size(name, index):
-    """`index`: who builds the search index.  The default (auto) builds it on the device from a
-    million triangles on - what the benchmark runs - and on the host below; "host" forces the
-    binned-SAH builder on the two scenes where auto does not take it."""
+    """`index`: who builds the search index.  The default (auto) builds it on the host below
+    rt.INDEX_AUTO_GPU_TRIANGLES triangles and on the device from there on - what the benchmark
+    runs; "host" / "gpu" force the other builder on the scenes where auto does not take it."""
     kind, level, copies, W, H, bounces, band = CASES[name]
     sc = rt.Scene()
     sc.push_synthetic(kind, level, copies, 12345)
@@ -64,7 +64,7 @@ def test_benchmark_workload_at_full_size(name, index):
     ro = rt.rand_origins(20221003, 2)
     osc = ol.scene_from_build(tris, nodes, W, H, rt.sobol_default_table(), sph, max_bounces=bounces)
 
-    build = rt.INDEX_BUILD_AUTO if index == "auto" else rt.INDEX_BUILD_HOST
+    build = {"auto": rt.INDEX_BUILD_AUTO, "host": rt.INDEX_BUILD_HOST, "gpu": rt.INDEX_BUILD_GPU}[index]
     r = rt.Renderer(W, H)
     r.set_options(index_build=build)
     r.upload(tris, nodes)
@@ -72,7 +72,7 @@ def test_benchmark_workload_at_full_size(name, index):
     r.set_camera(cam)
     r.set_options(max_bounces=bounces, index_build=build)   # defaults: persistent pipeline, search index
     info = r.scene_info()
-    assert info["index_built_on_device"] == int(index == "auto" and tris.shape[0] >= 1000000)
+    assert info["index_built_on_device"] == int(index == "gpu" or (index == "auto" and tris.shape[0] >= rt.INDEX_AUTO_GPU_TRIANGLES))
     # (v) what the benchmark runs: the 7-wave variant, an index deeper than its LDS stack
     assert info["triangles"] == tris.shape[0] >= 65536
     assert info["index_enabled"] == 1 and info["paths_waves_per_simd"] == 7
