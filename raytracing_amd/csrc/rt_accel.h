@@ -35,6 +35,11 @@ struct WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode layout");
 
+// log2 of the growth of the index's triangle boxes relative to the scene scale (times a shape
+// factor): INDEX_EPS_LOG2, or the experiment override RT_AMD_INDEX_EPS_LOG2.
+constexpr int INDEX_EPS_LOG2 = -18;
+int index_eps_log2();
+
 struct Accel {
     std::vector<AccelNode> nodes;
     std::vector<uint32_t> triIdx;   // triangle numbers (uploaded order) in leaf order

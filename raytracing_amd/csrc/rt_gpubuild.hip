@@ -43,7 +43,7 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) {     // 21 bits -> eve
     return x;
 }
 
-// Grown box of every triangle (the host builder's formula: eps = 2^-15 * scene scale * shape
+// Grown box of every triangle (the host builder's formula: eps = 2^INDEX_EPS_LOG2 * scene scale * shape
 // factor |A||B| / |A x B| clamped to 1..4096), and the Morton code of its centre.
 __global__ __launch_bounds__(BLOCK) void k_prims(const float4 *__restrict__ tris, const uint32_t n, const double epsBase,
                                                  const float3 smin, const float3 sinv, Box6 *__restrict__ boxes,
@@ -279,7 +279,7 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
     GB_TRY(hipMalloc(&keysSorted, (size_t)N * 8));
     GB_TRY(hipMalloc(&ids, (size_t)N * 4));
     GB_TRY(hipMalloc(&idsSorted, (size_t)N * 4));
-    hipLaunchKernelGGL(k_prims, dim3(blocksN), dim3(BLOCK), 0, st, dTris, (uint32_t)N, std::ldexp((double)sceneMaxAbs, -15), smin, sinv, prim, keys, ids);
+    hipLaunchKernelGGL(k_prims, dim3(blocksN), dim3(BLOCK), 0, st, dTris, (uint32_t)N, std::ldexp((double)sceneMaxAbs, index_eps_log2()), smin, sinv, prim, keys, ids);
     GB_TRY(hipGetLastError());
     if (N == 1) {
         // a single triangle: the root is a leaf, its box the triangle's grown box
