@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--resolution", default=None, help="WxH override for sensitivity runs (the named workload's resolution is the default)")
     ap.add_argument("--gpu-index", action="store_true", help="build the search index on the GPU at upload whatever the scene size")
     ap.add_argument("--host-index", action="store_true", help="build the search index on the host whatever the scene size "
-                    "(default: RtOptions.index_build = auto, on the GPU from four million triangles on)")
+                    "(default: RtOptions.index_build = auto, on the GPU from 16 million triangles on)")
     ap.add_argument("--no-overlap", action="store_true", help="keep every launch on the context's stream (RtOptions.overlap = 0)")
     ap.add_argument("--total-spp", type=int, default=0,
                     help="strong scaling: this many frames in the whole job, split evenly over ranks and steps "

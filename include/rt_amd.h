@@ -131,13 +131,13 @@ typedef struct RtOptions {
                                stream before a render call is not waited for by the rendering (none of it
                                is an input of the rendering).  0: everything runs on the context's stream. */
     int32_t index_build;    /* where rt_scene_upload builds the search index of `accel` (read at upload):
-                               RT_INDEX_BUILD_HOST: binned SAH on the host (0.5 s for 1.3M triangles, 4.3 s
-                               for 10.5M), the index that traces fastest (by 5 % on those two scenes, by
-                               12 % on a 262k-triangle interior); RT_INDEX_BUILD_GPU: Morton-order tree
-                               with size classes built on the device (0.1 s / 0.65 s including the
-                               upload); RT_INDEX_BUILD_AUTO (default): on the host below
+                               RT_INDEX_BUILD_HOST: binned SAH on the host (upload of 1.3M triangles in
+                               0.3 s, of 10.5M in 2.2 s), the index that traces fastest (by 5 % on those
+                               two scenes, by 15 % on a 262k-triangle interior); RT_INDEX_BUILD_GPU:
+                               Morton-order tree with size classes built on the device (0.1 s / 0.65 s);
+                               RT_INDEX_BUILD_AUTO (default): on the host below
                                RT_INDEX_AUTO_GPU_TRIANGLES triangles, on the device from there on, where
-                               the host build takes seconds.  Same images whichever builds it. */
+                               the host build takes several seconds.  Same images whichever builds it. */
     int32_t shading_normals; /* 0 (default): the reference's behaviour, the face normal of getTriangleNormal
                                (frag:296-300).  1: an extension the reference only prepares - its Triangle
                                carries n0 n1 n2 (frag:131, Model.h:101-112) and the comment on
@@ -151,7 +151,7 @@ typedef struct RtOptions {
 #define RT_INDEX_BUILD_HOST 0
 #define RT_INDEX_BUILD_GPU 1
 #define RT_INDEX_BUILD_AUTO 2
-#define RT_INDEX_AUTO_GPU_TRIANGLES 4000000
+#define RT_INDEX_AUTO_GPU_TRIANGLES 16000000
 #define RT_PIPELINE_WAVEFRONT 0   /* generate / extend / shade / accumulate kernels over ray queues */
 #define RT_PIPELINE_MEGAKERNEL 1  /* one thread per pixel runs the whole path */
 #define RT_PIPELINE_PERSISTENT 2  /* persistent waves; each lane runs whole paths and takes the next (frame, pixel)

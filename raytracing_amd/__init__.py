@@ -29,7 +29,7 @@ PIPELINE_PERSISTENT = 2
 INDEX_BUILD_HOST = 0
 INDEX_BUILD_GPU = 1
 INDEX_BUILD_AUTO = 2        # default: on the host below INDEX_AUTO_GPU_TRIANGLES triangles, on the device from there on
-INDEX_AUTO_GPU_TRIANGLES = 4000000
+INDEX_AUTO_GPU_TRIANGLES = 16000000
 
 # numpy views of the C structs of include/rt_amd.h
 TRIANGLE_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("n", "<f4", (3, 3)), ("tex", "<f4", (3, 2)),

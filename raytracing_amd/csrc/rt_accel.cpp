@@ -21,6 +21,8 @@
 // +1 % rays per second on 1.3M triangles of 8e-3 scene units and +4 % on 10M of 3e-3.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -35,8 +37,9 @@ namespace {
 
 constexpr int MAX_BINS = 64;     // measured: 16 -> 64 bins is 5 % fewer box tests per ray, more gives nothing
 
-struct Prim {
+struct Prim {               // the builder partitions these records themselves, so every scan is sequential
     float mn[3], mx[3], c[3];
+    uint32_t id;            // triangle number
 };
 
 struct Box {
@@ -59,8 +62,7 @@ struct TmpNode {
 
 struct Builder {
     int leafMax = 1;
-    const Prim *prims;
-    uint32_t *idx;
+    Prim *prims;
     std::vector<TmpNode> nodes;
     std::atomic<uint32_t> next{0};
 
@@ -70,7 +72,7 @@ struct Builder {
 
     Box bounds(int64_t begin, int64_t end) const {
         Box b; b.reset();
-        for (int64_t i = begin; i < end; i++) b.grow(prims[idx[i]].mn, prims[idx[i]].mx);
+        for (int64_t i = begin; i < end; i++) b.grow(prims[i].mn, prims[i].mx);
         return b;
     }
 
@@ -81,11 +83,10 @@ struct Builder {
     // split off while it is the small part (at most a tenth of the range).
     uint32_t build_by_size(int64_t begin, int64_t end, Box &box, float sceneExtent, int cls) {
         const int64_t count = end - begin;
-        if (cls >= 3 || count < 64) return build(begin, end, box, 3);
+        if (cls >= 3 || count < 64) return build(begin, end, box, 4);
         const float thr = sceneExtent * (cls == 0 ? 0.25f : (cls == 1 ? 0.0625f : 0.015625f));
-        uint32_t *first = idx + begin, *last = idx + end;
-        uint32_t *m = std::partition(first, last, [&](uint32_t id) {
-            const Prim &p = prims[id];
+        Prim *first = prims + begin, *last = prims + end;
+        Prim *m = std::partition(first, last, [&](const Prim &p) {
             return std::max(p.mx[0] - p.mn[0], std::max(p.mx[1] - p.mn[1], p.mx[2] - p.mn[2])) >= thr;
         });
         const int64_t nLarge = m - first;
@@ -99,28 +100,99 @@ struct Builder {
         return me;
     }
 
+    struct AxisBins { Box bb[MAX_BINS]; int64_t bc[MAX_BINS]; };
+    static constexpr int64_t PAR_COUNT = (int64_t)1 << 18;     // ranges from this size on are scanned on several threads
+
+    static int scan_threads(int64_t count) {
+        if (count < PAR_COUNT) return 1;
+        const int hw = (int)std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+        return (int)std::min<int64_t>(hw, count / (PAR_COUNT / 4));
+    }
+    template <typename Fn>
+    static void scan_chunks(int64_t begin, int64_t end, int threads, Fn fn) {     // fn(thread, chunk begin, chunk end)
+        if (threads <= 1) { fn(0, begin, end); return; }
+        std::vector<std::thread> pool;
+        const int64_t per = (end - begin + threads - 1) / threads;
+        for (int t = 0; t < threads; t++) {
+            const int64_t b = begin + t * per, e = std::min(end, b + per);
+            if (b >= e) break;
+            pool.emplace_back([=] { fn(t, b, e); });
+        }
+        for (auto &th : pool) th.join();
+    }
+    // box of the triangles and box of their centres (min/max are exact, so the split of the range
+    // over threads does not change the result)
+    void bounds2(int64_t begin, int64_t end, Box &box, Box &cb) const {
+        const int T = scan_threads(end - begin);
+        if (T <= 1) {
+            box.reset(); cb.reset();
+            for (int64_t i = begin; i < end; i++) { const Prim &p = prims[i]; box.grow(p.mn, p.mx); cb.grow(p.c, p.c); }
+            return;
+        }
+        std::vector<Box> pb((size_t)T), pc((size_t)T);
+        for (int t = 0; t < T; t++) { pb[(size_t)t].reset(); pc[(size_t)t].reset(); }
+        scan_chunks(begin, end, T, [&](int t, int64_t b, int64_t e) {
+            Box lb, lc; lb.reset(); lc.reset();
+            for (int64_t i = b; i < e; i++) { const Prim &p = prims[i]; lb.grow(p.mn, p.mx); lc.grow(p.c, p.c); }
+            pb[(size_t)t] = lb; pc[(size_t)t] = lc;
+        });
+        box.reset(); cb.reset();
+        for (int t = 0; t < T; t++) { box.grow(pb[(size_t)t]); cb.grow(pc[(size_t)t]); }
+    }
+    // the bins of the three axes in one pass
+    void bin_all(int64_t begin, int64_t end, const Box &cb, int NBINS, AxisBins out[3]) const {
+        float lo[3], scale[3]; bool use[3];
+        for (int ax = 0; ax < 3; ax++) {
+            const float ext = cb.mx[ax] - cb.mn[ax];
+            use[ax] = ext > 0.0f; lo[ax] = cb.mn[ax]; scale[ax] = use[ax] ? (float)NBINS / ext : 0.0f;
+        }
+        const int T = scan_threads(end - begin);
+        std::vector<AxisBins> part((size_t)(T > 1 ? 3 * T : 0));
+        auto clear = [&](AxisBins *a) { for (int ax = 0; ax < 3; ax++) for (int b = 0; b < NBINS; b++) { a[ax].bb[b].reset(); a[ax].bc[b] = 0; } };
+        clear(out);
+        scan_chunks(begin, end, T, [&](int t, int64_t b0, int64_t e0) {
+            AxisBins *dst = (T > 1) ? &part[(size_t)3 * t] : out;
+            if (T > 1) clear(dst);
+            for (int64_t i = b0; i < e0; i++) {
+                const Prim &p = prims[i];
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!use[ax]) continue;
+                    int b = (int)((p.c[ax] - lo[ax]) * scale[ax]);
+                    b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+                    dst[ax].bb[b].grow(p.mn, p.mx); dst[ax].bc[b]++;
+                }
+            }
+        });
+        if (T > 1)
+            for (int t = 0; t < T; t++)
+                for (int ax = 0; ax < 3; ax++)
+                    for (int b = 0; b < NBINS; b++) { out[ax].bb[b].grow(part[(size_t)3 * t + ax].bb[b]); out[ax].bc[b] += part[(size_t)3 * t + ax].bc[b]; }
+    }
+
     // Returns the ref of the subtree over idx[begin,end) and its box.
     uint32_t build(int64_t begin, int64_t end, Box &box, int fork) {
         const int64_t count = end - begin;
-        box = bounds(begin, end);
-        if (count <= 1) return leaf_ref(begin, count);
-        Box cb; cb.reset();
-        for (int64_t i = begin; i < end; i++) cb.grow(prims[idx[i]].c, prims[idx[i]].c);
+        if (count <= 1) { box = bounds(begin, end); return leaf_ref(begin, count); }
+        if (count == 2 && leafMax == 1) {       // nothing to choose: two leaves
+            const uint32_t me = next.fetch_add(1);
+            TmpNode nd;
+            nd.lbox.reset(); nd.lbox.grow(prims[begin].mn, prims[begin].mx);
+            nd.rbox.reset(); nd.rbox.grow(prims[begin + 1].mn, prims[begin + 1].mx);
+            nd.left = leaf_ref(begin, 1); nd.right = leaf_ref(begin + 1, 1);
+            nodes[me] = nd;
+            box = nd.lbox; box.grow(nd.rbox);
+            return me;
+        }
+        Box cb;
+        bounds2(begin, end, box, cb);
         // binned SAH over the three axes; small nodes need fewer bins to tell all their splits apart
         const int NBINS = (int)std::min<int64_t>(MAX_BINS, std::max<int64_t>(8, 4 * count));
         float bestCost = INFINITY; int bestAxis = -1, bestSplit = -1;
+        AxisBins bins[3];
+        bin_all(begin, end, cb, NBINS, bins);
         for (int ax = 0; ax < 3; ax++) {
-            const float lo = cb.mn[ax], ext = cb.mx[ax] - cb.mn[ax];
-            if (!(ext > 0.0f)) continue;
-            Box bb[MAX_BINS]; int64_t bc[MAX_BINS];
-            for (int b = 0; b < NBINS; b++) { bb[b].reset(); bc[b] = 0; }
-            const float scale = (float)NBINS / ext;
-            for (int64_t i = begin; i < end; i++) {
-                const Prim &p = prims[idx[i]];
-                int b = (int)((p.c[ax] - lo) * scale);
-                b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
-                bb[b].grow(p.mn, p.mx); bc[b]++;
-            }
+            if (!(cb.mx[ax] - cb.mn[ax] > 0.0f)) continue;
+            const Box *bb = bins[ax].bb; const int64_t *bc = bins[ax].bc;
             float rightArea[MAX_BINS]; int64_t rightCount[MAX_BINS];
             Box acc; acc.reset(); int64_t cnt = 0;
             for (int b = NBINS - 1; b > 0; b--) { acc.grow(bb[b]); cnt += bc[b]; rightArea[b] = acc.half_area(); rightCount[b] = cnt; }
@@ -143,9 +215,9 @@ struct Builder {
             mid = begin + count / 2;        // all centroids coincide: split by position in the list
         } else {
             const float lo = cb.mn[bestAxis], scale = (float)NBINS / (cb.mx[bestAxis] - cb.mn[bestAxis]);
-            uint32_t *first = idx + begin, *last = idx + end;
-            uint32_t *m = std::partition(first, last, [&](uint32_t id) {
-                int b = (int)((prims[id].c[bestAxis] - lo) * scale);
+            Prim *first = prims + begin, *last = prims + end;
+            Prim *m = std::partition(first, last, [&](const Prim &p) {
+                int b = (int)((p.c[bestAxis] - lo) * scale);
                 b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
                 return b <= bestSplit;
             });
@@ -170,69 +242,159 @@ struct Builder {
 };
 
 
+// fn(begin, end) over [0, n) on up to 16 threads
+template <typename Fn>
+void par_for(int64_t n, Fn fn) {
+    const int64_t minChunk = 16384;
+    const int threads = (int)std::min<int64_t>(std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u), (n + minChunk - 1) / minChunk);
+    if (threads <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        const int64_t b = t * per, e = std::min(n, b + per);
+        if (b >= e) break;
+        pool.emplace_back([=] { fn(b, e); });
+    }
+    for (auto &th : pool) th.join();
+}
+
 // Collapses the binary tree into 4-wide nodes: a wide node starts from the two children of a
 // binary node and repeatedly replaces its largest interior child by that child's two children.
+// First a serial walk that fixes the shape and the depth-first numbering (slot 0's subtree follows
+// its parent), then the boxes are quantised on all cores.
 void collapse_wide(const Builder &b, uint32_t root, Accel &out) {
-    struct Child { uint32_t ref; Box box; };
+    struct Shape { uint32_t ref[4]; uint32_t from[4]; uint8_t right[4]; uint8_t n; };     // child c: ref, and the binary node + side holding its box
     struct Item { uint32_t old; uint32_t parent; int slot; int depth; };
-    std::vector<Item> stack;
-    stack.push_back({root, 0xFFFFFFFFu, 0, 1});
-    out.wide.clear();
-    out.wide.reserve(b.nodes.size() / 2 + 1);
-    out.wideDepth = 0;
-    while (!stack.empty()) {
-        const Item it = stack.back(); stack.pop_back();
-        const uint32_t me = (uint32_t)out.wide.size();
-        out.wide.emplace_back();
-        if (it.parent != 0xFFFFFFFFu) out.wide[it.parent].ref[it.slot] = me;
-        if (it.depth > out.wideDepth) out.wideDepth = it.depth;
-        Child ch[4]; int n = 2;
-        ch[0] = {b.nodes[it.old].left, b.nodes[it.old].lbox};
-        ch[1] = {b.nodes[it.old].right, b.nodes[it.old].rbox};
+    auto box_of = [&](uint32_t from, uint8_t right) -> const Box & { return right ? b.nodes[from].rbox : b.nodes[from].lbox; };
+    // the (up to) four children of the wide node that stands for binary node `old`; interior refs are binary indices
+    auto shape_of = [&](uint32_t old) {
+        Shape sh;
+        int n = 2;
+        sh.ref[0] = b.nodes[old].left; sh.from[0] = old; sh.right[0] = 0;
+        sh.ref[1] = b.nodes[old].right; sh.from[1] = old; sh.right[1] = 1;
         while (n < 4) {
             int pick = -1; float area = -1.0f;
             for (int c = 0; c < n; c++)
-                if (!(ch[c].ref & ACCEL_LEAF_BIT) && ch[c].box.half_area() > area) { area = ch[c].box.half_area(); pick = c; }
+                if (!(sh.ref[c] & ACCEL_LEAF_BIT)) { const float a = box_of(sh.from[c], sh.right[c]).half_area(); if (a > area) { area = a; pick = c; } }
             if (pick < 0) break;
-            const TmpNode &src = b.nodes[ch[pick].ref];
-            ch[pick] = {src.left, src.lbox};
-            ch[n++] = {src.right, src.rbox};
+            const uint32_t src = sh.ref[pick];
+            sh.ref[pick] = b.nodes[src].left; sh.from[pick] = src; sh.right[pick] = 0;
+            sh.ref[n] = b.nodes[src].right; sh.from[n] = src; sh.right[n] = 1;
+            n++;
         }
-        Box nb; nb.reset();
-        for (int c = 0; c < n; c++) nb.grow(ch[c].box);
-        WideNode w;
-        std::memset(&w, 0, sizeof w);
-        double scale[3];
-        for (int k = 0; k < 3; k++) {
-            w.origin[k] = nb.mn[k];
-            const double ext = (double)nb.mx[k] - (double)nb.mn[k];
-            int e = (ext > 0.0) ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
-            e = std::min(std::max(e, -100), 100);
-            while (255.0 * std::ldexp(1.0, e) < ext) e++;
-            scale[k] = std::ldexp(1.0, e);
-            (k == 0 ? w.scaleX : (k == 1 ? w.scaleY : w.scaleZ)) = (float)scale[k];
+        for (int c = n; c < 4; c++) { sh.ref[c] = 0xFFFFFFFFu; sh.from[c] = 0; sh.right[c] = 0; }
+        sh.n = (uint8_t)n;
+        return sh;
+    };
+    // The top of the tree level by level, until there are enough subtrees to hand one to each thread ...
+    std::vector<Shape> shape;
+    std::vector<Item> frontier{{root, 0xFFFFFFFFu, 0, 1}};
+    int depthTop = 0;
+    while (!frontier.empty() && frontier.size() < 256) {
+        std::vector<Item> next;
+        for (const Item &it : frontier) {
+            const uint32_t me = (uint32_t)shape.size();
+            shape.push_back(shape_of(it.old));
+            if (it.parent != 0xFFFFFFFFu) shape[it.parent].ref[it.slot] = me;
+            if (it.depth > depthTop) depthTop = it.depth;
+            for (int c = 0; c < shape[me].n; c++)
+                if (!(shape[me].ref[c] & ACCEL_LEAF_BIT)) next.push_back({shape[me].ref[c], me, c, it.depth + 1});
         }
-        for (int c = 0; c < 4; c++) {
-            if (c >= n) {
-                w.ref[c] = 0xFFFFFFFFu;
-                for (int k = 0; k < 3; k++) { w.qlo[k] |= 255u << (8 * c); }
-                continue;
-            }
-            for (int k = 0; k < 3; k++) {
-                double lo = std::floor(((double)ch[c].box.mn[k] - (double)nb.mn[k]) / scale[k]);
-                double hi = std::ceil(((double)ch[c].box.mx[k] - (double)nb.mn[k]) / scale[k]);
-                lo = std::min(std::max(lo, 0.0), 255.0); hi = std::min(std::max(hi, 0.0), 255.0);
-                w.qlo[k] |= (uint32_t)lo << (8 * c);
-                w.qhi[k] |= (uint32_t)hi << (8 * c);
-            }
-            if (ch[c].ref & ACCEL_LEAF_BIT) w.ref[c] = ACCEL_LEAF_BIT | out.triIdx[ch[c].ref & 0x0FFFFFFFu];
-            else w.ref[c] = ch[c].ref;      // binary index for now; patched when the child is emitted
-        }
-        out.wide[me] = w;
-        // children are emitted depth first; slot 0's subtree follows its parent
-        for (int c = n - 1; c >= 0; c--)
-            if (!(ch[c].ref & ACCEL_LEAF_BIT)) stack.push_back({ch[c].ref, me, c, it.depth + 1});
+        frontier.swap(next);
     }
+    // ... then every subtree depth first (slot 0's subtree follows its parent), numbered from 0 within itself
+    const size_t nSub = frontier.size();
+    std::vector<std::vector<Shape>> sub(nSub);
+    std::vector<int> subDepth(nSub, 0);
+    std::atomic<size_t> nextSub{0};
+    auto worker = [&]() {
+        std::vector<Item> stack;
+        for (size_t j = nextSub.fetch_add(1); j < nSub; j = nextSub.fetch_add(1)) {
+            std::vector<Shape> &loc = sub[j];
+            int deepest = 0;
+            stack.clear();
+            stack.push_back({frontier[j].old, 0xFFFFFFFFu, 0, frontier[j].depth});
+            while (!stack.empty()) {
+                const Item it = stack.back(); stack.pop_back();
+                const uint32_t me = (uint32_t)loc.size();
+                loc.push_back(shape_of(it.old));
+                if (it.parent != 0xFFFFFFFFu) loc[it.parent].ref[it.slot] = me;
+                if (it.depth > deepest) deepest = it.depth;
+                for (int c = loc[me].n - 1; c >= 0; c--)
+                    if (!(loc[me].ref[c] & ACCEL_LEAF_BIT)) stack.push_back({loc[me].ref[c], me, c, it.depth + 1});
+            }
+            subDepth[j] = deepest;
+        }
+    };
+    {
+        const int threads = (int)std::min<size_t>(std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u), std::max<size_t>(nSub, 1));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    // one array: the top, then the subtrees in frontier order; local numbers become global ones
+    std::vector<size_t> start(nSub + 1, shape.size());
+    for (size_t j = 0; j < nSub; j++) start[j + 1] = start[j] + sub[j].size();
+    const size_t nTop = shape.size();
+    shape.resize(start[nSub]);
+    out.wideDepth = depthTop;
+    for (size_t j = 0; j < nSub; j++) {
+        shape[frontier[j].parent].ref[frontier[j].slot] = (uint32_t)start[j];
+        out.wideDepth = std::max(out.wideDepth, subDepth[j]);
+    }
+    par_for((int64_t)nSub, [&](int64_t jb, int64_t je) {
+        for (int64_t j = jb; j < je; j++) {
+            const uint32_t off = (uint32_t)start[(size_t)j];
+            for (size_t k = 0; k < sub[(size_t)j].size(); k++) {
+                Shape sh = sub[(size_t)j][k];
+                for (int c = 0; c < sh.n; c++)
+                    if (!(sh.ref[c] & ACCEL_LEAF_BIT)) sh.ref[c] += off;
+                shape[off + k] = sh;
+            }
+            std::vector<Shape>().swap(sub[(size_t)j]);
+        }
+    });
+    (void)nTop;
+    out.wide.assign(shape.size(), WideNode());
+    par_for((int64_t)shape.size(), [&](int64_t wb, int64_t we) {
+        for (int64_t me = wb; me < we; me++) {
+            const Shape &sh = shape[(size_t)me];
+            const int n = sh.n;
+            Box nb; nb.reset();
+            for (int c = 0; c < n; c++) nb.grow(box_of(sh.from[c], sh.right[c]));
+            WideNode w;
+            std::memset(&w, 0, sizeof w);
+            double scale[3];
+            for (int k = 0; k < 3; k++) {
+                w.origin[k] = nb.mn[k];
+                const double ext = (double)nb.mx[k] - (double)nb.mn[k];
+                int e = (ext > 0.0) ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+                e = std::min(std::max(e, -100), 100);
+                while (255.0 * std::ldexp(1.0, e) < ext) e++;
+                scale[k] = std::ldexp(1.0, e);
+                (k == 0 ? w.scaleX : (k == 1 ? w.scaleY : w.scaleZ)) = (float)scale[k];
+            }
+            for (int c = 0; c < 4; c++) {
+                if (c >= n) {
+                    w.ref[c] = 0xFFFFFFFFu;
+                    for (int k = 0; k < 3; k++) { w.qlo[k] |= 255u << (8 * c); }
+                    continue;
+                }
+                const Box &cb = box_of(sh.from[c], sh.right[c]);
+                for (int k = 0; k < 3; k++) {
+                    double lo = std::floor(((double)cb.mn[k] - (double)nb.mn[k]) / scale[k]);
+                    double hi = std::ceil(((double)cb.mx[k] - (double)nb.mn[k]) / scale[k]);
+                    lo = std::min(std::max(lo, 0.0), 255.0); hi = std::min(std::max(hi, 0.0), 255.0);
+                    w.qlo[k] |= (uint32_t)lo << (8 * c);
+                    w.qhi[k] |= (uint32_t)hi << (8 * c);
+                }
+                if (sh.ref[c] & ACCEL_LEAF_BIT) w.ref[c] = ACCEL_LEAF_BIT | out.triIdx[sh.ref[c] & 0x0FFFFFFFu];
+                else w.ref[c] = sh.ref[c];
+            }
+            out.wide[(size_t)me] = w;
+        }
+    });
     out.wideRootRef = 0;
     out.wideStack = 3 * out.wideDepth + 1;
 }
@@ -247,9 +409,13 @@ int index_eps_log2() {
 int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMax, Accel &out) {
     out = Accel();
     if (n <= 0 || n >= ((int64_t)1 << 28)) return RT_E_INVALID;
+    const bool verbose = getenv("RT_AMD_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tStart = now();
     std::vector<Prim> prims((size_t)n);
     const double epsBase = std::ldexp((double)sceneMaxAbs, index_eps_log2());
-    for (int64_t i = 0; i < n; i++) {
+    par_for(n, [&](int64_t ib, int64_t ie) {
+    for (int64_t i = ib; i < ie; i++) {
         const RtTriangle &t = tris[i];
         Prim &p = prims[(size_t)i];
         // shape factor |A||B| / |A x B| (1 for a right-angled corner, large for slivers)
@@ -267,12 +433,13 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMa
             p.mn[k] = lo - eps; p.mx[k] = hi + eps;
             p.c[k] = 0.5f * lo + 0.5f * hi;
         }
+        p.id = (uint32_t)i;
     }
-    out.triIdx.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) out.triIdx[(size_t)i] = (uint32_t)i;
+    });
+    const double tPrims = now();
     Builder b;
     b.leafMax = std::min(std::max(leafMax, 1), 8);
-    b.prims = prims.data(); b.idx = out.triIdx.data();
+    b.prims = prims.data();
     b.nodes.resize((size_t)std::max<int64_t>(n - 1, 1));
     Box rootBox;
     uint32_t root;
@@ -284,12 +451,24 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMa
         root = b.build_by_size(0, n, rootBox, ext, 0);
     }
     for (int k = 0; k < 3; k++) { out.rootMin[k] = rootBox.mn[k]; out.rootMax[k] = rootBox.mx[k]; }
+    out.triIdx.resize((size_t)n);       // triangle numbers in leaf order
+    par_for(n, [&](int64_t ib, int64_t ie) { for (int64_t i = ib; i < ie; i++) out.triIdx[(size_t)i] = prims[(size_t)i].id; });
+    const double tBuilt = now();
     const uint32_t used = b.next.load();
-    // Relayout in depth-first order (a left child follows its parent) and measure the depth.
-    out.nodes.resize(used);
     out.maxDepth = 0;
     out.directLeaves = (b.leafMax == 1);
     if (root & ACCEL_LEAF_BIT) { out.rootRef = out.directLeaves ? (ACCEL_LEAF_BIT | out.triIdx[root & 0x0FFFFFFFu]) : root; return RT_OK; }
+    if (out.directLeaves) {
+        // one triangle per leaf (what the GPU kernels read): only the 4-wide form is kept
+        out.rootRef = 0;
+        collapse_wide(b, root, out);
+        if (verbose)
+            fprintf(stderr, "rt_amd: host index build: boxes %.0f ms, SAH tree %.0f ms, 4-wide collapse %.0f ms\n",
+                    tPrims - tStart, tBuilt - tPrims, now() - tBuilt);
+        return RT_OK;
+    }
+    // Binary form, relaid in depth-first order (a left child follows its parent).
+    out.nodes.resize(used);
     struct Item { uint32_t old; uint32_t parentNew; int side; int depth; };
     std::vector<Item> stack;
     stack.push_back({root, 0xFFFFFFFFu, 0, 1});
@@ -317,7 +496,6 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMa
         if (!(src.left & ACCEL_LEAF_BIT)) stack.push_back({src.left, me, 0, it.depth + 1});
     }
     out.rootRef = 0;
-    if (out.directLeaves) collapse_wide(b, root, out);
     return RT_OK;
 }
 

@@ -50,7 +50,7 @@ def _rays_for(tris, seed, n=50000):
 
 
 @pytest.mark.parametrize("name,index", [("dragon1m", "auto"), ("dragon1m", "gpu"), ("sponza", "auto"),
-                                        ("stress10m", "auto"), ("stress10m", "host"), ("stress3m9", "auto")])
+                                        ("stress10m", "auto"), ("stress10m", "gpu"), ("stress3m9", "auto")])
 def test_benchmark_workload_at_full_size(name, index):
     """`index`: who builds the search index.  The default (auto) builds it on the host below
     rt.INDEX_AUTO_GPU_TRIANGLES triangles and on the device from there on - what the benchmark

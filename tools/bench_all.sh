@@ -7,7 +7,7 @@ python bench.py --workload demo --no-cpu-baseline > $O/demo.json 2>> $O/err.log 
 python bench.py --workload sponza --no-cpu-baseline > $O/sponza.json 2>> $O/err.log || exit 1
 python bench.py --workload stress10m --no-cpu-baseline > $O/stress10m.json 2>> $O/err.log || exit 1
 python bench.py --no-cpu-baseline --no-call-granularity --gpu-index > $O/dragon1m_gpu_index.json 2>> $O/err.log || exit 1
-python bench.py --no-cpu-baseline --no-call-granularity --workload stress10m --host-index > $O/stress10m_host_index.json 2>> $O/err.log || exit 1
+python bench.py --no-cpu-baseline --no-call-granularity --workload stress10m --gpu-index > $O/stress10m_gpu_index.json 2>> $O/err.log || exit 1
 python bench.py --no-cpu-baseline --no-call-granularity --workload sponza --gpu-index > $O/sponza_gpu_index.json 2>> $O/err.log || exit 1
 python bench.py --no-cpu-baseline --no-call-granularity --no-overlap > $O/dragon1m_no_overlap.json 2>> $O/err.log || exit 1
 python bench.py --no-cpu-baseline --no-call-granularity --no-accel > $O/dragon1m_reference_order.json 2>> $O/err.log || exit 1
