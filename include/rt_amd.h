@@ -147,6 +147,16 @@ typedef struct RtOptions {
                                turned to the side of the face normal; a triangle whose normals are zero
                                keeps its face normal.  The scene must have been uploaded with this
                                option already set (the normals are only copied to the GPU then). */
+    int32_t albedo_texture; /* 0 (default): the reference's behaviour.  1: a second extension the reference
+                               only prepares - its Triangle carries uv0 uv1 uv2 (frag:132, Model.h:117-124)
+                               and its loader reads a material's diffuse maps (Model.h:167-169), but the
+                               shader never samples them: the albedo of a diffuse draw (frag:466-468)
+                               becomes kd * texel of the image given to rt_set_albedo_texture, at the
+                               texture coordinates RtTriangle.tex interpolated at the hit point (weights
+                               as for shading_normals, divided by their sum), wrapped as GL_REPEAT
+                               (Model.h:244-245), nearest texel.  Lights, mirrors, glass and the spheres
+                               are not affected.  The scene must have been uploaded with this option
+                               already set (the coordinates are only copied to the GPU then). */
 } RtOptions;
 #define RT_INDEX_BUILD_HOST 0
 #define RT_INDEX_BUILD_GPU 1
@@ -291,6 +301,12 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n,
  * floats per record, records contiguous). */
 int rt_scene_upload_textures(RtContext *ctx, const float *tex_triangle, int64_t n,
                              const float *tex_bvh, int64_t m);
+/* The image of RtOptions.albedo_texture: width x height texels of 3 bytes (GL_RGB,
+ * GL_UNSIGNED_BYTE, tightly packed; row 0 is the row at v = 0, the order glTexImage2D takes them in,
+ * Model.h:241), copied to the GPU.  width, height in 1..16384.  rgb == NULL removes the image.
+ * Stands where TextureFromFile (Model.h:220-258) stands in the reference, without the file
+ * decoding (stb_image there): the caller passes decoded texels. */
+int rt_set_albedo_texture(RtContext *ctx, const uint8_t *rgb, int width, int height);
 /* setSobol, sobol.h:27-34. */
 int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]);
 /* Scene::setSphere, Scene.h:71-85 (count <= 10). */

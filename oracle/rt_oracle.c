@@ -102,6 +102,14 @@ typedef struct {
                                    n0 n1 n2, frag:131, and the comment above getTriangleNormal, frag:295,
                                    marks it as to be changed to interpolation): shade with the
                                    interpolated vertex normals, see shading_normal() below. */
+    const uint8_t *albedoTex;   /* NULL: the reference's behaviour.  Otherwise a second extension of the same
+                                   kind: the Triangle struct carries uv0 uv1 uv2 (frag:132) and the loader
+                                   reads the diffuse maps of a material (Model.h:167-169), but the shader
+                                   never samples them.  albedoTexW x albedoTexH texels of 3 bytes (GL_RGB,
+                                   GL_UNSIGNED_BYTE, row 0 at v = 0, as glTexImage2D takes them,
+                                   Model.h:241); the albedo of a diffuse draw becomes kd * texel, see
+                                   albedo_texel() below. */
+    int albedoTexW, albedoTexH;
 } OrScene;
 
 typedef struct {
@@ -171,7 +179,7 @@ typedef struct {                                                 /* frag:242-250
     float roughness, refraction, rayHitMin;
 } HitRecord;
 
-typedef struct { v3 v0, v1, v2, ka, kd, ks, n0, n1, n2; } Tri;   /* used fields of frag:128-133; n0..n2 only with shadingNormals */
+typedef struct { v3 v0, v1, v2, ka, kd, ks, n0, n1, n2; float uv[3][2]; } Tri;   /* used fields of frag:128-133; n0..n2 only with shadingNormals, uv only with albedoTex */
 
 typedef struct {
     const OrScene *sc;
@@ -278,6 +286,9 @@ static Tri get_triangle(const OrScene *sc, int offset) {
         t.n1 = V3(At(T, W, o + 11), At(T, W, o + 12), At(T, W, o + 13));
         t.n2 = V3(At(T, W, o + 19), At(T, W, o + 20), At(T, W, o + 21));
     }
+    memset(t.uv, 0, sizeof t.uv);
+    if (sc->albedoTex)
+        for (int k = 0; k < 3; k++) { t.uv[k][0] = At(T, W, o + 8 * k + 6); t.uv[k][1] = At(T, W, o + 8 * k + 7); }
     return t;
 }
 
@@ -343,6 +354,33 @@ static v3 shading_normal(const Tri *tri, v3 P, v3 faceNormal) {
     n = vscale(n, 1.0f / sqrtf(l2));
     if (dot3(n, faceNormal) < 0.0f) n = vneg(n);
     return n;
+}
+
+/* albedoTex != NULL (not in the reference, see OrScene).  The texture coordinate is the
+ * barycentric mean of uv0 uv1 uv2 with the weights of shading_normal() (the edge functions of
+ * hitTriangle at the hit position), divided by their sum.  Wrapping is GL_REPEAT
+ * (Model.h:244-245): the fractional part c - floor(c); the filter is GL_NEAREST like the
+ * tracer's own data textures (ObjectTexture.h:127-128; the trilinear filter of Model.h:246-247
+ * belongs to a rasteriser with screen-space derivatives): texel floor(frac * size), clamped to
+ * size - 1 (the fraction of a tiny negative coordinate rounds to 1).  A coordinate that is not
+ * finite (degenerate weights) reads texel (0,0).  A byte b is the colour b / 255. */
+static v3 albedo_texel(const OrScene *sc, const Tri *tri, v3 P) {
+    v3 N = normalize3(cross3(vsub(tri->v1, tri->v0), vsub(tri->v2, tri->v0)));
+    float w2 = dot3(N, cross3(vsub(tri->v1, tri->v0), vsub(P, tri->v0)));
+    float w0 = dot3(N, cross3(vsub(tri->v2, tri->v1), vsub(P, tri->v1)));
+    float w1 = dot3(N, cross3(vsub(tri->v0, tri->v2), vsub(P, tri->v2)));
+    float sum = (w0 + w1) + w2;
+    int xy[2];
+    for (int k = 0; k < 2; k++) {
+        float c = MADD(w2, tri->uv[2][k], MADD(w1, tri->uv[1][k], w0 * tri->uv[0][k])) / sum;
+        int size = k ? sc->albedoTexH : sc->albedoTexW;
+        if (!(fabsf(c) < INFINITY)) c = 0.0f;
+        float frac = c - floorf(c);
+        int i = (int)(frac * (float)size);
+        xy[k] = i > size - 1 ? size - 1 : i;
+    }
+    const uint8_t *px = sc->albedoTex + ((size_t)xy[1] * (size_t)sc->albedoTexW + (size_t)xy[0]) * 3;
+    return V3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
 }
 
 /* frag:306-331.  getBoundp(b,i) = i==0 ? pMin : pMax. */
@@ -419,6 +457,7 @@ static int hit_bvh(Px *p, Ray ray) {
         } else if (temp < tri.ks.x) {
             rec->materialIndex = 1;
             rec->albedo = tri.kd;
+            if (sc->albedoTex) rec->albedo = vmul(tri.kd, albedo_texel(sc, &tri, rec->Pos));
         } else if (temp < tri.ks.y) {
             rec->materialIndex = 2;
             rec->albedo = V3(1.0f, 1.0f, 1.0f);

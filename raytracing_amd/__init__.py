@@ -69,7 +69,7 @@ class RtSceneInfo(C.Structure):
 class RtOptions(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
                 ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32), ("overlap", C.c_int32),
-                ("index_build", C.c_int32), ("shading_normals", C.c_int32)]
+                ("index_build", C.c_int32), ("shading_normals", C.c_int32), ("albedo_texture", C.c_int32)]
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
@@ -113,6 +113,7 @@ _PROTOS = {
     "rt_scene_upload": (_int, [_vp, _vp, _i64, _vp, _i64]),
     "rt_scene_upload_textures": (_int, [_vp, _vp, _i64, _vp, _i64]),
     "rt_set_sobol": (_int, [_vp, _vp]),
+    "rt_set_albedo_texture": (_int, [_vp, _vp, _int, _int]),
     "rt_set_spheres": (_int, [_vp, _vp, _int]),
     "rt_set_camera": (_int, [_vp, _vp]),
     "rt_render_frames": (_int, [_vp, _int, _int, _vp]),
@@ -313,9 +314,9 @@ class Renderer:
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
     def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True,
-                    history8=False, overlap=True, index_build=2, shading_normals=False):
+                    history8=False, overlap=True, index_build=2, shading_normals=False, albedo_texture=False):
         o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8), int(overlap), int(index_build),
-                      int(shading_normals))
+                      int(shading_normals), int(albedo_texture))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 
     def upload(self, tris, nodes):
@@ -327,6 +328,17 @@ class Renderer:
         tt = np.ascontiguousarray(tex_triangle, dtype=np.float32)
         tb = np.ascontiguousarray(tex_bvh, dtype=np.float32)
         _check(lib.rt_scene_upload_textures(self._h, _ptr(tt), n, _ptr(tb), m), self._h)
+
+    def set_albedo_texture(self, rgb):
+        """rgb: (H, W, 3) uint8, row 0 at v = 0 (the order glTexImage2D takes rows in); None removes it.
+        Used by renders with set_options(albedo_texture=True)."""
+        if rgb is None:
+            _check(lib.rt_set_albedo_texture(self._h, None, 0, 0), self._h)
+            return
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise ValueError("albedo texture must be (H, W, 3) uint8")
+        _check(lib.rt_set_albedo_texture(self._h, _ptr(rgb), rgb.shape[1], rgb.shape[0]), self._h)
 
     def set_sobol(self, v):
         v = np.ascontiguousarray(v, dtype=np.uint32)

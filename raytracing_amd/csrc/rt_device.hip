@@ -58,7 +58,7 @@ __device__ __forceinline__ void flush_counters(WorkCounters *wc, uint32_t rays, 
 // ------------------------------------------------------------------ megakernel
 
 // One thread per pixel, `count` frames per launch; accumulators stay in registers.
-template <bool CULL, bool COUNT, bool VNRM = false>
+template <bool CULL, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const FrameD F, const int firstLoopNum,
                                                       const int count, const float *__restrict__ randOrigin,
                                                       const uint32_t *__restrict__ sobV,
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_megakernel(const SceneD S, const Fram
                 if (COUNT && tri != REF_NONE) cHit++;
                 float su, sv;
                 sobol_pair(sobV, loopNum, (uint32_t)b, su, sv);
-                if (!shade_hit<VNRM>(F, S, p, t, tri, b, su, sv, px, py, sample)) break;
+                if (!shade_hit<EXT>(F, S, p, t, tri, b, su, sv, px, py, sample)) break;
             }
             // frag:697 with an fp32 history, and the plain sum
             const float n = (float)(int)loopNum;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_fast(const SceneD S, const Pat
 
 // shade: one thread per ray of the current queue; finished paths write their sample,
 // continuing paths are compacted into the next queue.
-template <bool VNRM>
+template <bool EXT>
 __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F, const int bounce, const uint32_t loopNum,
                                                  const uint32_t *__restrict__ sobV, const PathSoA Qin, const uint32_t cap, const uint32_t *__restrict__ qcountIn,
                                                  const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri,
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
             pix = Qin.pix[slot];
             const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
             vec3 sample;
-            goOn = shade_hit<VNRM>(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, px, py, sample);
+            goOn = shade_hit<EXT>(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, px, py, sample);
             if (!goOn && (sample.x != 0.0f || sample.y != 0.0f || sample.z != 0.0f)) {
                 const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
                 cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
@@ -430,7 +430,7 @@ __global__ void k_sobol_table(const BatchD B, const int maxBounces, const uint32
 //
 // FAST: closest hit through the search index with the proof/re-trace of k_extend_fast;
 // otherwise the reference's tree in the reference's order (Trav<CULL>).
-template <bool FAST, bool CULL, bool COUNT, int OCC, bool VNRM = false>
+template <bool FAST, bool CULL, bool COUNT, int OCC, bool EXT = false>
 __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_paths(const SceneD S, const FrameD F, const BatchD B,
                                                  const float *__restrict__ sob, uint32_t *__restrict__ workHead, float *__restrict__ cur,
                                                  WorkCounters *__restrict__ wc) {
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 Path p;
                 p.o = tv.o; p.d = tv.d; p.thr = thr; p.seed = seed;
                 vec3 sample;
-                const bool goOn = shade_hit<VNRM>(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], px, py, sample);
+                const bool goOn = shade_hit<EXT>(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], px, py, sample);
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
@@ -746,6 +746,9 @@ struct RtContext {
     // scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dMats = nullptr;
     float4 *dVNrm = nullptr;            // vertex normals, only when the scene was uploaded with shading_normals set
+    float4 *dUVs = nullptr;             // texture coordinates, only when the scene was uploaded with albedo_texture set
+    uint8_t *dTexels = nullptr;         // rt_set_albedo_texture
+    int texW = 0, texH = 0;
     float4 *dANodes = nullptr;                                  // search index: nodes
     uint32_t *dAOvf[NSLOT] = {};                               // overflow of the deferred-node stack, one per launch slot
     int accelLdsEntries = 16;
@@ -1036,6 +1039,7 @@ int rt_default_options(RtOptions *out) {
     out->overlap = 1;
     out->index_build = RT_INDEX_BUILD_AUTO;
     out->shading_normals = 0;
+    out->albedo_texture = 0;
     return RT_OK;
 }
 
@@ -1112,6 +1116,7 @@ void rt_destroy(RtContext *ctx) {
     for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->freeEvents) hipEventDestroy(e);
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dVNrm);
+    hipFree(ctx->dUVs); hipFree(ctx->dTexels);
     hipFree(ctx->dANodes);
     for (auto &p : ctx->dAOvf) hipFree(p);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
@@ -1144,6 +1149,8 @@ int rt_set_options(RtContext *ctx, const RtOptions *opt) {
     if (opt->index_build != RT_INDEX_BUILD_HOST && opt->index_build != RT_INDEX_BUILD_GPU && opt->index_build != RT_INDEX_BUILD_AUTO) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown index_build");
     if (opt->shading_normals != 0 && ctx->haveScene && !ctx->dVNrm)
         return fail(ctx, RT_E_STATE, "rt_set_options: shading_normals needs a scene uploaded with the option already set");
+    if (opt->albedo_texture != 0 && ctx->haveScene && !ctx->dUVs)
+        return fail(ctx, RT_E_STATE, "rt_set_options: albedo_texture needs a scene uploaded with the option already set");
     ctx->opt = *opt;
     ctx->frame.maxBounces = opt->max_bounces;
     return RT_OK;
@@ -1176,8 +1183,8 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     if (wantIndex && !gpuBuild) host_build();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dVNrm);
-    ctx->dVNrm = nullptr;
+    hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dVNrm); hipFree(ctx->dUVs);
+    ctx->dVNrm = nullptr; ctx->dUVs = nullptr;
     for (auto &p : ctx->dAOvf) { hipFree(p); p = nullptr; }
     ctx->dNodes = ctx->dTris = ctx->dMats = ctx->dANodes = nullptr; ctx->haveScene = false;
     const size_t nodeBytes = std::max<size_t>(hNodes.size(), 4) * sizeof(float4);
@@ -1200,6 +1207,18 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         });
         HIP_TRY(ctx, hipMalloc(&ctx->dVNrm, hVN.size() * sizeof(float4)));
         HIP_TRY(ctx, hipMemcpy(ctx->dVNrm, hVN.data(), hVN.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    if (ctx->opt.albedo_texture) {
+        std::vector<float4> hUV((size_t)n * 2);
+        parallel_for(n, [&](int64_t ib, int64_t ie) {
+            for (int64_t i = ib; i < ie; i++) {
+                const RtTriangle &t = tris[i];
+                hUV[(size_t)i * 2 + 0] = make_float4(t.tex[0][0], t.tex[0][1], t.tex[1][0], t.tex[1][1]);
+                hUV[(size_t)i * 2 + 1] = make_float4(t.tex[2][0], t.tex[2][1], 0.0f, 0.0f);
+            }
+        });
+        HIP_TRY(ctx, hipMalloc(&ctx->dUVs, hUV.size() * sizeof(float4)));
+        HIP_TRY(ctx, hipMemcpy(ctx->dUVs, hUV.data(), hUV.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
     S.anodes = nullptr; S.arootRef = REF_NONE; S.aovf = nullptr; S.aovfStride = 0; S.aovfRetrace = 0; S.aldsEntries = 1;
     uint32_t indexNodes = 0; int indexStackNeed = 0;
@@ -1295,6 +1314,24 @@ int rt_scene_upload_textures(RtContext *ctx, const float *tex_triangle, int64_t 
     return rt_scene_upload(ctx, tris.data(), n, nodes.data(), m);
 }
 
+int rt_set_albedo_texture(RtContext *ctx, const uint8_t *rgb, int width, int height) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_set_albedo_texture: null context");
+    if (rgb && (width < 1 || height < 1 || width > 16384 || height > 16384))
+        return fail(ctx, RT_E_INVALID, "rt_set_albedo_texture: width/height must be in 1..16384");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // kernels of earlier render calls may still read the old image
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sl : ctx->slot)
+        if (sl.stream) HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+    hipFree(ctx->dTexels); ctx->dTexels = nullptr; ctx->texW = ctx->texH = 0;
+    if (!rgb) return RT_OK;
+    const size_t bytes = (size_t)width * (size_t)height * 3;
+    HIP_TRY(ctx, hipMalloc(&ctx->dTexels, bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->dTexels, rgb, bytes, hipMemcpyHostToDevice));
+    ctx->texW = width; ctx->texH = height;
+    return RT_OK;
+}
+
 int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]) {
     if (!ctx || !v) return fail(ctx, RT_E_INVALID, "rt_set_sobol: null pointer");
     std::memcpy(ctx->sobol, v, sizeof ctx->sobol);
@@ -1351,9 +1388,15 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     if (ctx->pendingEvents.size() > 8192) { rc = resolve_events(ctx); if (rc != RT_OK) return rc; }
     const FrameD &F = ctx->frame;
     SceneD S = ctx->scene;
-    const bool vnrm = ctx->opt.shading_normals != 0;
+    const bool vnrm = ctx->opt.shading_normals != 0, tex = ctx->opt.albedo_texture != 0;
     if (vnrm && !ctx->dVNrm) return fail(ctx, RT_E_STATE, "rt_render_frames: shading_normals needs a scene uploaded with the option already set");
+    if (tex && !ctx->dUVs) return fail(ctx, RT_E_STATE, "rt_render_frames: albedo_texture needs a scene uploaded with the option already set");
+    if (tex && !ctx->dTexels) return fail(ctx, RT_E_STATE, "rt_render_frames: albedo_texture is set but rt_set_albedo_texture gave no image");
     S.vnrm = vnrm ? ctx->dVNrm : nullptr;
+    S.uvs = tex ? ctx->dUVs : nullptr;
+    S.texels = tex ? ctx->dTexels : nullptr;
+    S.texW = ctx->texW; S.texH = ctx->texH;
+    const bool ext = vnrm || tex;       // the kernels with the shading extensions
     const int tiles = ((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
     const int tileBlocks = (tiles + BLOCK / 64 - 1) / (BLOCK / 64);
     const size_t lds = stack_bytes(ctx);
@@ -1374,7 +1417,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
         HIP_TRY(ctx, hipEventRecord(e0, st));
 #define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters)
-        if (vnrm) {     // shading with vertex normals: the counting instantiations only
+        if (ext) {     // shading extensions: the counting instantiations only
             if (cull) hipLaunchKernelGGL((k_megakernel<true, true, true>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters);
             else hipLaunchKernelGGL((k_megakernel<false, true, true>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters);
         }
@@ -1399,7 +1442,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         const bool overlap = ctx->opt.overlap != 0;
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
-        const int occ = vnrm ? 5 : paths_occupancy(ctx);
+        const int occ = ext ? 5 : paths_occupancy(ctx);
         const int blocks = ctx->numCU * (fast ? occ : 5) * (BLOCK / PATHS_BLOCK);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
         if (overlap && !ctx->inputEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->inputEvent, hipEventDisableTiming));
@@ -1444,7 +1487,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             HIP_TRY(ctx, hipEventRecord(e0, ps));
 #define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(PATHS_BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
 #define LAUNCH_PATHS_VN(A, C) hipLaunchKernelGGL((k_paths<A, C, true, 5, true>), dim3(blocks), dim3(PATHS_BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
-            if (vnrm) {     // shading with vertex normals: the counting instantiations only
+            if (ext) {     // shading extensions: the counting instantiations only
                 if (fast) LAUNCH_PATHS_VN(true, true); else if (cull) LAUNCH_PATHS_VN(false, true); else LAUNCH_PATHS_VN(false, false);
             }
 #undef LAUNCH_PATHS_VN
@@ -1507,7 +1550,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             }
             HIP_TRY(ctx, hipEventRecord(e1, st));
             ctx->pendingEvents.emplace_back(e0, e1);
-            if (vnrm) hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
+            if (ext) hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
                                          ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
             else hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
                                     ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);

@@ -22,6 +22,8 @@
 //          on the triangle only.
 //   vnrm:  only with RtOptions.shading_normals: one 48-byte record per triangle, the vertex
 //          normals n0 n1 n2 (frag:131), read once per final hit.
+//   uvs:   only with RtOptions.albedo_texture: one 32-byte record per triangle, the texture
+//          coordinates uv0 uv1 uv2 (frag:132), read once per final hit, and the texels of the image.
 // The reference's 33-float triangle texel and 9-float node texel carry 15 resp. 0 floats the
 // shader never uses (normals, uvs: frag:196-218).
 #pragma once
@@ -66,6 +68,10 @@ struct SceneD {
     float arootMax[3];
     float originLimit;      // rays starting farther than this from the origin skip the index
     unsigned long long *timeline;   // experiment builds (RT_EXP_TIMELINE): per wave start, end, rays, iterations
+    // RtOptions.albedo_texture, else nullptr
+    const float4 *uvs;      // 2 x float4 per triangle: uv0 uv1 | uv2 pad pad
+    const uint8_t *texels;  // texW x texH x 3 bytes, row 0 at v = 0
+    int32_t texW, texH;
 };
 
 struct FrameD {

@@ -3,7 +3,7 @@
 //   rt_render [--demo | --obj FILE SX SY SZ TX TY TZ ... | --synthetic KIND LEVEL COPIES]
 //             [--sphere CX CY CZ R AR AG AB DIFFUSE_RATE MIRROR_RATE] [--size W H] [--spp N]
 //             [--bounces B] [--seed S] [--camera PX PY PZ YAW PITCH FOV] [--exact] [--megakernel | --wavefront] [--history8]
-//             [--shading-normals] [--gpu-index | --host-index]
+//             [--shading-normals] [--texture image.ppm] [--gpu-index | --host-index]
 //             [--out image.pfm] [--ppm image.ppm]
 //
 // Loads the scene (Model + Scene::pushModel), builds the BVH in the reference's node order
@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
     uint32_t seed = 20221003u;
     bool exact = false, mega = false, wavefront = false, history8 = false, shadingNormals = false, gpuIndex = false, hostIndex = false, customCam = false, haveGeometry = false;
     float camArgs[6] = {0, 2, 5, -90, 0, 45};
-    std::string outPfm, outPpm;
+    std::string outPfm, outPpm, texturePpm;
     RtScene *scene = nullptr;
     if (rt_scene_create(&scene) != RT_OK) return die("rt_scene_create", nullptr);
     for (int i = 1; i < argc; i++) {
@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
         else if (a == "--wavefront") wavefront = true;
         else if (a == "--history8") history8 = true;
         else if (a == "--shading-normals") shadingNormals = true;     // interpolated vertex normals (not in the reference)
+        else if (a == "--texture") { need(1); texturePpm = argv[++i]; }  // diffuse albedo map at the models' vt coordinates (not in the reference)
         else if (a == "--gpu-index") gpuIndex = true;                 // search index built on the device
         else if (a == "--host-index") hostIndex = true;               // ... on the host (default: by scene size)
         else if (a == "--out") { need(1); outPfm = argv[++i]; }
@@ -96,11 +97,42 @@ int main(int argc, char **argv) {
     opt.accel = exact ? 0 : 1;
     opt.history8 = history8 ? 1 : 0;      // the reference keeps its running mean in an 8-bit texture (RT_Screen.h:61)
     opt.shading_normals = shadingNormals ? 1 : 0;
+    opt.albedo_texture = texturePpm.empty() ? 0 : 1;
     opt.index_build = gpuIndex ? RT_INDEX_BUILD_GPU : (hostIndex ? RT_INDEX_BUILD_HOST : RT_INDEX_BUILD_AUTO);
     opt.pipeline = mega ? RT_PIPELINE_MEGAKERNEL : (wavefront ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_PERSISTENT);
     // before the upload: index_build and shading_normals are read there
     if (rt_set_options(ctx, &opt) != RT_OK) return die("rt_set_options", ctx);
     if (rt_scene_upload(ctx, tris.data(), n, nodes.data(), m) != RT_OK) return die("rt_scene_upload", ctx);   // getTexture, main.cpp:120
+    if (!texturePpm.empty()) {
+        // binary PPM, 8 bits per channel.  Rows go to the library in file order (top row first), as
+        // stbi_load hands them to glTexImage2D in TextureFromFile (Model.h:229-241); the loader has
+        // flipped v like aiProcess_FlipUVs (Model.h:58), so the image appears upright.
+        FILE *f = std::fopen(texturePpm.c_str(), "rb");
+        if (!f) { std::perror(texturePpm.c_str()); return 1; }
+        int tw = 0, th = 0, maxv = 0;
+        auto next_int = [&](int &v) {
+            int c = std::fgetc(f);
+            while (c == '#' || c == ' ' || c == '\n' || c == '\r' || c == '\t') {
+                if (c == '#') while (c != '\n' && c != EOF) c = std::fgetc(f);
+                else c = std::fgetc(f);
+            }
+            v = 0;
+            bool any = false;
+            while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); any = true; if (v > 1 << 20) return false; c = std::fgetc(f); }
+            return any;     // the one whitespace character after the number is consumed
+        };
+        const bool magic = std::fgetc(f) == 'P' && std::fgetc(f) == '6';
+        if (!magic || !next_int(tw) || !next_int(th) || !next_int(maxv) || maxv != 255 || tw < 1 || th < 1 || tw > 16384 || th > 16384) {
+            std::fprintf(stderr, "rt_render: %s: not a binary PPM (P6) with 8 bits per channel, at most 16384 x 16384\n", texturePpm.c_str());
+            std::fclose(f);
+            return 1;
+        }
+        std::vector<uint8_t> texels((size_t)tw * th * 3);
+        const size_t got = std::fread(texels.data(), 1, texels.size(), f);
+        std::fclose(f);
+        if (got != texels.size()) { std::fprintf(stderr, "rt_render: %s: file ends early\n", texturePpm.c_str()); return 1; }
+        if (rt_set_albedo_texture(ctx, texels.data(), tw, th) != RT_OK) return die("rt_set_albedo_texture", ctx);
+    }
     std::vector<RtSphere> spheres((size_t)rt_scene_sphere_count(scene));
     if (!spheres.empty() && rt_scene_get_spheres(scene, spheres.data(), (int)spheres.size()) != RT_OK) return die("scene spheres", nullptr);
     if (rt_set_spheres(ctx, spheres.data(), (int)spheres.size()) != RT_OK) return die("rt_set_spheres", ctx);     // scene.setSphere, main.cpp:169

@@ -83,9 +83,11 @@ __host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tan
 // opens the next iteration (frag:625-630).  sobU/sobV are the frame's Sobol numbers for this
 // bounce (sobol_pair).  Returns true when the path goes on (p holds the next ray); otherwise
 // `sample` is the frame's radiance for the pixel.
-// VNRM: shade with interpolated vertex normals (RtOptions.shading_normals); kernels that do so
-// are separate instantiations, so the default ones pay neither registers nor branches for it.
-template <bool VNRM = false>
+// EXT: the extensions RtOptions.shading_normals (S.vnrm set: shade with interpolated vertex
+// normals) and RtOptions.albedo_texture (S.texels set: diffuse albedo times a texel); kernels
+// that offer them are separate instantiations, so the default ones pay neither registers nor
+// branches for them.
+template <bool EXT = false>
 __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
                                           int bounce, float sobU, float sobV, uint32_t pixX, uint32_t pixY, vec3 &sample) {
     sample = rtm::mk(0.0f, 0.0f, 0.0f);
@@ -101,28 +103,48 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
     vec3 bitangent = rtm::mk(m3.w, m4.x, m4.y);
     bool recFrame = true;
     if (rtm::dot(nrm, p.d) > 0.0f) { nrm = rtm::neg(nrm); tangent = rtm::neg(tangent); }
-    if constexpr (VNRM) if (triHit) {
-        // RtOptions.shading_normals: vertex normals interpolated with the edge functions of
-        // hitTriangle (frag:265-275) at the hit position, normalised, turned to the side of
-        // the face normal; a zero, infinite or NaN sum keeps the face normal
+    vec3 texel = rtm::mk(1.0f, 1.0f, 1.0f);
+    if constexpr (EXT) if (triHit) {
+        // both extensions weigh the vertex attributes with the edge functions of hitTriangle
+        // (frag:265-275) at the hit position: w0 belongs to v0 (edge v1->v2), w1 to v1, w2 to v2
         const float4 *g = S.tris + (size_t)tri * TRI_RECORD;
         const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-        const float4 *vn = S.vnrm + (size_t)tri * 3;
-        const float4 a0 = vn[0], a1 = vn[1], a2 = vn[2];
         const vec3 v0 = rtm::mk(g0.x, g0.y, g0.z), v1 = rtm::mk(g0.w, g1.x, g1.y), v2 = rtm::mk(g1.z, g1.w, g2.x);
         const vec3 N = rtm::mk(g2.y, g2.z, g2.w);
         const float w2 = rtm::dot(N, rtm::cross(rtm::sub(v1, v0), rtm::sub(pos, v0)));
         const float w0 = rtm::dot(N, rtm::cross(rtm::sub(v2, v1), rtm::sub(pos, v1)));
         const float w1 = rtm::dot(N, rtm::cross(rtm::sub(v0, v2), rtm::sub(pos, v2)));
-        vec3 n = rtm::mk(rtm::madd(w2, a1.z, rtm::madd(w1, a0.w, w0 * a0.x)),
-                         rtm::madd(w2, a1.w, rtm::madd(w1, a1.x, w0 * a0.y)),
-                         rtm::madd(w2, a2.x, rtm::madd(w1, a1.y, w0 * a0.z)));
-        const float l2 = rtm::dot(n, n);
-        if ((l2 > 0.0f) && (l2 < INFINITY)) {
-            n = rtm::scale(n, rtm::rsqrt_exact(l2));
-            if (rtm::dot(n, nrm) < 0.0f) n = rtm::neg(n);
-            nrm = n;
-            recFrame = false;
+        if (S.vnrm) {
+            // RtOptions.shading_normals: the interpolated vertex normal, normalised, turned to the
+            // side of the face normal; a zero, infinite or NaN sum keeps the face normal
+            const float4 *vn = S.vnrm + (size_t)tri * 3;
+            const float4 a0 = vn[0], a1 = vn[1], a2 = vn[2];
+            vec3 n = rtm::mk(rtm::madd(w2, a1.z, rtm::madd(w1, a0.w, w0 * a0.x)),
+                             rtm::madd(w2, a1.w, rtm::madd(w1, a1.x, w0 * a0.y)),
+                             rtm::madd(w2, a2.x, rtm::madd(w1, a1.y, w0 * a0.z)));
+            const float l2 = rtm::dot(n, n);
+            if ((l2 > 0.0f) && (l2 < INFINITY)) {
+                n = rtm::scale(n, rtm::rsqrt_exact(l2));
+                if (rtm::dot(n, nrm) < 0.0f) n = rtm::neg(n);
+                nrm = n;
+                recFrame = false;
+            }
+        }
+        if (S.texels) {
+            // RtOptions.albedo_texture: texture coordinate = weighted mean of uv0 uv1 uv2, wrapped
+            // as GL_REPEAT (fractional part), nearest texel; a coordinate that is not finite reads
+            // texel 0; a byte b is the colour b / 255
+            const float4 *uq = S.uvs + (size_t)tri * 2;
+            const float4 u0 = uq[0], u1 = uq[1];
+            const float sum = (w0 + w1) + w2;
+            float cu = rtm::madd(w2, u1.x, rtm::madd(w1, u0.z, w0 * u0.x)) / sum;
+            float cv = rtm::madd(w2, u1.y, rtm::madd(w1, u0.w, w0 * u0.y)) / sum;
+            if (!(fabsf(cu) < INFINITY)) cu = 0.0f;
+            if (!(fabsf(cv) < INFINITY)) cv = 0.0f;
+            const int tx = min((int)((cu - floorf(cu)) * (float)S.texW), S.texW - 1);
+            const int ty = min((int)((cv - floorf(cv)) * (float)S.texH), S.texH - 1);
+            const uint8_t *px = S.texels + ((size_t)ty * (size_t)S.texW + (size_t)tx) * 3;
+            texel = rtm::mk((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
         }
     }
     uint32_t seedT = p.seed;
@@ -134,7 +156,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
     vec3 albedo = rtm::mk(1.0f, 1.0f, 1.0f);
     float refraction = 1.0f;
     if (rtm::dot(ka, ka) > 0.0f) { material = 0; albedo = ka; }                 // length(ka) > 0
-    else if (tempT < ksx) { material = 1; albedo = kd; }
+    else if (tempT < ksx) { material = 1; albedo = EXT ? rtm::mul(kd, texel) : kd; }
     else if (tempT < ksy) { material = 2; }
     else { material = 3; refraction = 1.5f; }
     bool hit = triHit && tTri > 0.0f && tTri < HIT_MIN_INIT;                    // frag:562-565

@@ -40,7 +40,8 @@ class OrScene(C.Structure):
                 ("V", C.c_void_p),
                 ("sphere", OrSphere * 10), ("sphereNum", C.c_int),
                 ("maxBounces", C.c_int), ("trigMode", C.c_int), ("bvhInts", C.c_void_p),
-                ("shadingNormals", C.c_int)]
+                ("shadingNormals", C.c_int),
+                ("albedoTex", C.c_void_p), ("albedoTexW", C.c_int), ("albedoTexH", C.c_int)]
 
 
 class OrStats(C.Structure):
@@ -133,7 +134,7 @@ class OracleScene:
 
     def __init__(self, tex_tri, tex_tri_w, ntri, tex_bvh, tex_bvh_w, nnode, width, height,
                  sobol_v, spheres=None, max_bounces=4, trig_mode=1, fused=True, bvh_ints=None,
-                 shading_normals=False):
+                 shading_normals=False, albedo_texture=None):
         self.lib = load(fused)
         self._tt = np.ascontiguousarray(tex_tri, dtype=np.float32)
         self._tb = np.ascontiguousarray(tex_bvh, dtype=np.float32)
@@ -163,6 +164,12 @@ class OracleScene:
         self._ints = None if bvh_ints is None else np.ascontiguousarray(bvh_ints, dtype=np.int32)
         s.bvhInts = None if self._ints is None else self._ints.ctypes.data
         s.shadingNormals = int(shading_normals)
+        # albedo_texture: (H, W, 3) uint8, row 0 at v = 0
+        self._tex = None if albedo_texture is None else np.ascontiguousarray(albedo_texture, dtype=np.uint8)
+        if self._tex is not None:
+            assert self._tex.ndim == 3 and self._tex.shape[2] == 3
+            s.albedoTex = self._tex.ctypes.data
+            s.albedoTexH, s.albedoTexW = self._tex.shape[0], self._tex.shape[1]
         self.s = s
         self.width, self.height = width, height
 

@@ -692,6 +692,66 @@ def test_shading_with_interpolated_vertex_normals(golden_dir, tmp_path):
     r.close()
 
 
+def test_albedo_texture_at_interpolated_texture_coordinates(golden_dir, tmp_path):
+    """RtOptions.albedo_texture (the reference's Triangle carries uv0 uv1 uv2, frag:132, and its
+    loader reads diffuse maps, Model.h:167-169, but the shader never samples one): every pipeline
+    against the oracle in the same mode, on a model with `vt` corners whose coordinates are
+    stretched beyond [0,1] and below 0 (GL_REPEAT); together with shading_normals; off again on
+    the same context; and the call-order errors."""
+    import os
+    _globe_obj(str(tmp_path / "globe.obj"))
+    W, H = 150, 100
+    sc = rt.Scene()
+    sc.push_obj(os.path.join(golden_dir, "objects", "room.obj"), (5.0, 5.0, 5.0), (0.0, 5.0, 0.0))
+    sc.push_obj(str(tmp_path / "globe.obj"), (1.8, 1.8, 1.8), (-0.5, 2.0, 0.5))
+    t = sc.triangles()
+    t["tex"] = t["tex"] * np.float32(3.7) - np.float32(1.3)
+    t["tex"][:20] = t["v"][:20][:, :, [0, 2]] * np.float32(0.23) + t["v"][:20][:, :, [1, 1]] * np.float32(0.31)   # the room: from positions
+    tris, nodes = rt.bvh_build(t)
+    image = np.random.default_rng(11).integers(0, 256, (23, 37, 3)).astype(np.uint8)
+    cam = rt.CameraRig(W, H).uniforms()
+    ro = rt.rand_origins(20221003, 3)
+    flat, _ = _oracle_for(tris, nodes, W, H, None).render(cam, 1, ro)
+    want, st = _oracle_for(tris, nodes, W, H, None, albedo_texture=image).render(cam, 1, ro, want_stats=True)
+    both, _ = _oracle_for(tris, nodes, W, H, None, albedo_texture=image, shading_normals=True).render(cam, 1, ro)
+    assert not _same_image(flat, want) and not _same_image(both, want)
+    for name, pipeline, accel in (("paths", rt.PIPELINE_PERSISTENT, True), ("paths_ref_order", rt.PIPELINE_PERSISTENT, False),
+                                  ("wavefront", rt.PIPELINE_WAVEFRONT, True), ("mega", rt.PIPELINE_MEGAKERNEL, False)):
+        r = rt.Renderer(W, H)
+        r.set_options(pipeline=pipeline, accel=accel, albedo_texture=True, shading_normals=True)
+        r.upload(tris, nodes)
+        r.set_camera(cam)
+        with pytest.raises(rt.RtError, match="rt_set_albedo_texture"):
+            r.render(1, ro)
+        r.set_albedo_texture(image)
+        r.render(1, ro)
+        assert _same_image(r.read_mean(), both), name
+        r.set_options(pipeline=pipeline, accel=accel, albedo_texture=True)
+        r.reset()
+        r.render(1, ro)
+        assert _same_image(r.read_mean(), want), name
+        assert r.stats()["rays"] == st["rays"], name
+        # another image on the same context, then the option off again: the reference's albedo
+        r.set_albedo_texture(np.full((2, 2, 3), 255, np.uint8))
+        r.reset()
+        r.render(1, ro)
+        assert _same_image(r.read_mean(), flat), name
+        r.set_albedo_texture(image)
+        r.set_options(pipeline=pipeline, accel=accel)
+        r.reset()
+        r.render(1, ro)
+        assert _same_image(r.read_mean(), flat), name
+        r.close()
+    # a scene uploaded without the option has no texture coordinates on the GPU
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    with pytest.raises(rt.RtError, match="albedo_texture"):
+        r.set_options(albedo_texture=True)
+    with pytest.raises(rt.RtError, match="width/height"):
+        r.set_albedo_texture(np.zeros((0, 4, 3), np.uint8))
+    r.close()
+
+
 def test_sweep_built_tree_renders_like_the_oracle_on_the_same_tree():
     """The build mode the reference's author left commented out (BVH.h:225-256) gives another
     node order; the shader semantics on that tree are the same, so every pipeline must match the
@@ -804,3 +864,20 @@ def test_cxx_host_program_matches_python_path(tmp_path):
     assert np.array_equal(got, r.read_mean())
     ppm = open(tmp_path / "img.ppm", "rb").read()
     assert ppm.startswith(b"P6\n%d %d\n255\n" % (W, H)) and len(ppm) == len(b"P6\n%d %d\n255\n" % (W, H)) + W * H * 3
+    # --texture: a binary PPM sampled at the model's vt coordinates (RtOptions.albedo_texture)
+    _globe_obj(str(tmp_path / "globe.obj"))
+    image = np.random.default_rng(3).integers(0, 256, (9, 14, 3)).astype(np.uint8)
+    open(tmp_path / "tex.ppm", "wb").write(b"P6\n# made by the test\n14 9\n255\n" + image.tobytes())
+    subprocess.check_call([exe, "--obj", str(tmp_path / "globe.obj"), "2", "2", "2", "0", "2", "0", "--texture", str(tmp_path / "tex.ppm"),
+                           "--size", str(W), str(H), "--spp", str(spp), "--out", str(out)])
+    got = np.frombuffer(open(out, "rb").read()[len(header):], dtype="<f4").reshape(H, W, 3)
+    sc = rt.Scene()
+    sc.push_obj(str(tmp_path / "globe.obj"), (2.0, 2.0, 2.0), (0.0, 2.0, 0.0))
+    tris, nodes = rt.bvh_build(sc.triangles())
+    r = rt.Renderer(W, H)
+    r.set_options(albedo_texture=True)
+    r.upload(tris, nodes)
+    r.set_albedo_texture(image)
+    r.set_camera(rt.camera_default(W, H))
+    r.render(1, rt.rand_origins(20221003, spp))
+    assert np.array_equal(got, r.read_mean())

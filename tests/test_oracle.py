@@ -121,3 +121,37 @@ def test_shading_normal_mode_of_the_oracle():
     t["n"] *= -1.0
     back, _ = ol.scene_from_build(t, nodes, W, H, V, sc.spheres(), shading_normals=True).render(cam, 1, ro)
     assert np.array_equal(np.nan_to_num(back), np.nan_to_num(tilted))
+
+
+def test_albedo_texture_mode_of_the_oracle():
+    """OrScene.albedoTex: a white image leaves every pixel as in the reference's mode; a one-texel
+    image is the same as scaling every kd by that colour (lights keep ka); texture coordinates
+    wrap as GL_REPEAT: a triangle whose three corners carry the same coordinate reads the texel
+    of its fractional part whatever whole number is added."""
+    import raytracing_amd as rt
+    import scenes
+    W, H = 64, 40
+    sc = scenes.demo()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 2)
+    V = rt.sobol_default_table()
+    eq = lambda a, b: np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    render = lambda t, **kw: ol.scene_from_build(t, nodes, W, H, V, sc.spheres(), **kw).render(cam, 1, ro)[0]
+    flat = render(tris)
+    assert eq(render(tris, albedo_texture=np.full((3, 5, 3), 255, np.uint8)), flat)
+    colour = np.array([51, 102, 255], dtype=np.uint8)
+    scaled = tris.copy()
+    scaled["kd"] = tris["kd"] * (colour.astype(np.float32) / np.float32(255.0))
+    one = render(tris, albedo_texture=colour.reshape(1, 1, 3))
+    assert eq(one, render(scaled)) and not eq(one, flat)
+    # two texels side by side; every triangle sits in the middle of one of them, some whole numbers away
+    rng = np.random.default_rng(5)
+    two = np.array([[[200, 30, 90], [10, 250, 120]]], dtype=np.uint8)
+    pick = rng.integers(0, 2, tris.shape[0])
+    t = tris.copy()
+    t["tex"][:, :, 0] = (0.25 + 0.5 * pick + rng.integers(-3, 4, tris.shape[0]))[:, None]
+    t["tex"][:, :, 1] = rng.integers(-2, 3, tris.shape[0])[:, None] + 0.5
+    scaled = tris.copy()
+    scaled["kd"] = tris["kd"] * (two[0, pick].astype(np.float32) / np.float32(255.0))
+    assert eq(render(t, albedo_texture=two), render(scaled))
