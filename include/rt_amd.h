@@ -134,7 +134,7 @@ typedef struct RtOptions {
                                RT_INDEX_BUILD_HOST: binned SAH on the host (upload of 1.3M triangles in
                                0.3 s, of 10.5M in 2.2 s), the index that traces fastest (by 5 % on those
                                two scenes, by 15 % on a 262k-triangle interior); RT_INDEX_BUILD_GPU:
-                               Morton-order tree with size classes built on the device (0.1 s / 0.65 s);
+                               tree clustered in Morton order with size classes on the device (0.1 s / 0.6 s);
                                RT_INDEX_BUILD_AUTO (default): on the host below
                                RT_INDEX_AUTO_GPU_TRIANGLES triangles, on the device from there on, where
                                the host build takes several seconds.  Same images whichever builds it. */

@@ -1,14 +1,15 @@
 // GPU-side construction of the search index of the extend stage (see rt_accel.cpp for what the
 // index is and why any conservative index gives the reference's image).
 //
-// The host builder (rt_accel.cpp, binned SAH) takes 0.8 s for 1.3M triangles and 4.5 s for 10M.
-// This one builds a linear BVH on the device in a few milliseconds: triangle boxes and 63-bit
-// Morton codes of their centres, a radix sort, the binary radix tree of Karras (one thread per
-// internal node), a bottom-up refit, and a level-by-level collapse into the same 4-wide nodes with
-// 8-bit quantised child boxes that the traversal kernels read (rt_accel.h WideNode).  The boxes
-// are grown and quantised with the host builder's formulas, so the search stays conservative.
-// A Morton-order tree is not as good as a SAH tree (more boxes per ray), so this is the build
-// for callers that upload often; RtOptions.index_build selects it.
+// The host builder (rt_accel.cpp, binned SAH) takes 0.2 s for 1.3M triangles and 1.5 s for 10M.
+// This one builds on the device in a few milliseconds: triangle boxes and 63-bit Morton codes of
+// their centres, a radix sort, agglomerative clustering of neighbours in that order (parallel
+// locally-ordered clustering) into a binary tree, and a level-by-level collapse into the same
+// 4-wide nodes with 8-bit quantised child boxes that the traversal kernels read (rt_accel.h
+// WideNode).  The boxes are grown and quantised with the host builder's formulas, so the search
+// stays conservative.  The tree is not as good as the host's top-down SAH tree (5-15 % more boxes
+// per ray; a Karras radix tree over the same order, which this build replaced, had 3 % more
+// again), so this is the build for callers that upload often; RtOptions.index_build selects it.
 //
 // The reference has no counterpart: its only tree is the median split of BVH.h:188-264, built
 // on the CPU (its author's alternative split, BVH.h:225-256, is rt_bvh_build_sweep).
@@ -18,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "rt_accel.h"
@@ -88,87 +90,100 @@ __global__ __launch_bounds__(BLOCK) void k_prims(const float4 *__restrict__ tris
     ids[i] = i;
 }
 
-// Common leading bits of the keys at sorted positions i and j (equal keys: told apart by position).
-__device__ __forceinline__ int delta(const uint64_t *__restrict__ keys, const int n, const int i, const int j) {
-    if (j < 0 || j >= n) return -1;
-    const uint64_t a = keys[i], b = keys[j];
-    if (a == b) return 64 + __clz((unsigned)(i ^ j));
-    return __clzll((long long)(a ^ b));
-}
-
-// Karras, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees" (2012):
-// internal node i of the binary radix tree over the sorted keys.  Child refs: LEAF | sorted
-// position, or an internal index.
-__global__ __launch_bounds__(BLOCK) void k_hierarchy(const uint64_t *__restrict__ keys, const int n, uint32_t *__restrict__ left,
-                                                     uint32_t *__restrict__ right, uint32_t *__restrict__ parentOfInternal,
-                                                     uint32_t *__restrict__ parentOfLeaf) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n - 1) return;
-    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-    const int dmin = delta(keys, n, i, i - d);
-    int lmax = 2;
-    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
-    int l = 0;
-    for (int t = lmax >> 1; t >= 1; t >>= 1)
-        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-    const int j = i + l * d;
-    const int dnode = delta(keys, n, i, j);
-    int s = 0, t = l;
-    do {
-        t = (t + 1) >> 1;
-        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-    } while (t > 1);
-    const int gamma = i + s * d + (d < 0 ? d : 0);
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    const uint32_t L = (lo == gamma) ? (LEAF | (uint32_t)gamma) : (uint32_t)gamma;
-    const uint32_t R = (hi == gamma + 1) ? (LEAF | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-    left[i] = L; right[i] = R;
-    if (L & LEAF) parentOfLeaf[gamma] = (uint32_t)i; else parentOfInternal[gamma] = (uint32_t)i;
-    if (R & LEAF) parentOfLeaf[gamma + 1] = (uint32_t)i; else parentOfInternal[gamma + 1] = (uint32_t)i;
-    if (i == 0) parentOfInternal[0] = 0xFFFFFFFFu;
-}
-
 __device__ __forceinline__ Box6 child_box(const uint32_t ref, const Box6 *__restrict__ prim, const uint32_t *__restrict__ ids,
                                           const Box6 *nodeBox) {
     return (ref & LEAF) ? prim[ids[ref & ~LEAF]] : nodeBox[ref];
 }
 
-// The same inside the refit kernel, where an internal box was written by another workgroup moments
-// ago: read past this CU's vector cache (a neighbouring entry may have brought the line in earlier).
-__device__ __forceinline__ Box6 child_box_fresh(const uint32_t ref, const Box6 *__restrict__ prim, const uint32_t *__restrict__ ids,
-                                                const Box6 *nodeBox) {
-    if (ref & LEAF) return prim[ids[ref & ~LEAF]];
-    const volatile float *p = (const volatile float *)&nodeBox[ref];
-    Box6 b;
-    for (int k = 0; k < 3; k++) { b.mn[k] = p[k]; b.mx[k] = p[3 + k]; }
-    return b;
-}
-
-// Boxes of the internal nodes, bottom up: the second thread to arrive at a node computes it.
-__global__ __launch_bounds__(BLOCK) void k_refit(const int n, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
-                                                 const uint32_t *__restrict__ parentOfInternal, const uint32_t *__restrict__ parentOfLeaf,
-                                                 const Box6 *__restrict__ prim, const uint32_t *__restrict__ ids,
-                                                 Box6 *nodeBox, uint32_t *arrivals) {
-    const int s = blockIdx.x * BLOCK + threadIdx.x;
-    if (s >= n) return;
-    uint32_t cur = parentOfLeaf[s];
-    while (cur != 0xFFFFFFFFu) {
-        __threadfence();
-        if (atomicAdd(&arrivals[cur], 1u) == 0u) return;
-        __threadfence();
-        const Box6 a = child_box_fresh(left[cur], prim, ids, nodeBox), b = child_box_fresh(right[cur], prim, ids, nodeBox);
-        Box6 u;
-        for (int k = 0; k < 3; k++) { u.mn[k] = fminf(a.mn[k], b.mn[k]); u.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
-        // written so that the other CUs see it (the reader is whoever arrives second at the parent)
-        volatile float *o = (volatile float *)&nodeBox[cur];
-        for (int k = 0; k < 3; k++) { o[k] = u.mn[k]; o[3 + k] = u.mx[k]; }
-        cur = parentOfInternal[cur];
-    }
-}
-
 __device__ __forceinline__ float half_area(const Box6 &b) {
     const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
     return (dx < 0.0f) ? 0.0f : dx * dy + dy * dz + dz * dx;
+}
+
+__device__ __forceinline__ Box6 box_union(const Box6 &a, const Box6 &b) {
+    Box6 u;
+    for (int k = 0; k < 3; k++) { u.mn[k] = fminf(a.mn[k], b.mn[k]); u.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+    return u;
+}
+
+// ---- agglomerative build: parallel locally-ordered clustering (Meister and Bittner, "Parallel
+// locally-ordered clustering for bounding volume hierarchy construction", 2018).  The clusters
+// (at first the triangles in Morton order) each look for the neighbour within PLOC_RADIUS positions
+// whose union with them has the smallest area; pairs that chose each other merge into a new
+// binary node, the others stay, the array is compacted in order, and so on until one is left.
+
+constexpr int PLOC_RADIUS = 16;
+constexpr int PLOC_RADIUS_MAX = 128;
+
+// nearest[i]: position of the neighbour of cluster i with the smallest union.  A tile of boxes is
+// staged in LDS.  Ties go to the lower position, and an area that is not finite counts as the
+// largest float, so the choice is a total order and some pair always chooses each other.
+__global__ __launch_bounds__(BLOCK) void k_ploc_nearest(const uint32_t count, const int radius, const Box6 *__restrict__ cbox, uint32_t *__restrict__ nearest) {
+    __shared__ Box6 tile[BLOCK + 2 * PLOC_RADIUS_MAX];
+    const int first = (int)(blockIdx.x * BLOCK) - radius;
+    for (int t = threadIdx.x; t < BLOCK + 2 * radius; t += BLOCK) {
+        const int j = first + t;
+        if (j >= 0 && j < (int)count) tile[t] = cbox[j];
+    }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
+    if (i >= (int)count) return;
+    const Box6 mine = tile[threadIdx.x + radius];
+    float best = INFINITY; int bestJ = -1;
+    for (int d = -radius; d <= radius; d++) {
+        const int j = i + d;
+        if (d == 0 || j < 0 || j >= (int)count) continue;
+        float a = half_area(box_union(mine, tile[threadIdx.x + radius + d]));
+        if (!(a < 3.0e38f)) a = 3.0e38f;
+        if (a < best) { best = a; bestJ = j; }
+    }
+    nearest[i] = (uint32_t)bestJ;
+}
+
+// flags[i]: low word 1 if position i survives the round (unmerged, or the lower position of a
+// merging pair), high word 1 if it is the lower position of a merging pair.
+__global__ __launch_bounds__(BLOCK) void k_ploc_flags(const uint32_t count, const uint32_t *__restrict__ nearest, uint64_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t j = nearest[i];
+    const bool mutual = nearest[j] == i;
+    flags[i] = (mutual && j < i) ? 0ull : ((mutual ? 1ull << 32 : 0ull) | 1ull);
+}
+
+// Writes the next round's clusters at their scanned positions; merging pairs become binary node
+// nodeBase + (rank among the merges).  state: [0] clusters left, [1] binary nodes made so far.
+__global__ __launch_bounds__(BLOCK) void k_ploc_merge(const uint32_t count, const uint32_t nodeBase, const uint32_t *__restrict__ nearest,
+                                                      const uint64_t *__restrict__ flags, const uint64_t *__restrict__ scan,
+                                                      const uint32_t *__restrict__ cl, const Box6 *__restrict__ cbox,
+                                                      uint32_t *__restrict__ clOut, Box6 *__restrict__ cboxOut,
+                                                      uint32_t *__restrict__ left, uint32_t *__restrict__ right, Box6 *__restrict__ nodeBox,
+                                                      uint32_t *__restrict__ state) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t f = flags[i], ps = scan[i];
+    const uint32_t pos = (uint32_t)ps, rank = (uint32_t)(ps >> 32);
+    if (f >> 32) {
+        const uint32_t j = nearest[i], node = nodeBase + rank;
+        const Box6 u = box_union(cbox[i], cbox[j]);
+        left[node] = cl[i]; right[node] = cl[j]; nodeBox[node] = u;
+        clOut[pos] = node; cboxOut[pos] = u;
+    } else if (f & 1ull) {
+        clOut[pos] = cl[i]; cboxOut[pos] = cbox[i];
+    }
+    if (i == count - 1u) {
+        const uint64_t total = ps + f;
+        state[0] = (uint32_t)total;
+        state[1] = nodeBase + (uint32_t)(total >> 32);
+    }
+}
+
+// The clusters of the first round: the triangles in sorted order.
+__global__ __launch_bounds__(BLOCK) void k_ploc_init(const uint32_t n, const Box6 *__restrict__ prim, const uint32_t *__restrict__ ids,
+                                                     uint32_t *__restrict__ cl, Box6 *__restrict__ cbox) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    cl[i] = LEAF | i;
+    cbox[i] = prim[ids[i]];
 }
 
 // One level of the collapse: every item (binary node, wide slot) of the frontier becomes a
@@ -240,8 +255,8 @@ __global__ __launch_bounds__(BLOCK) void k_collapse(const int level, const uint2
     }
 }
 
-__global__ void k_seed_frontier(uint2 *frontier, uint32_t *counters) {
-    frontier[0] = make_uint2(0u, 0u);       // binary root -> wide slot 0
+__global__ void k_seed_frontier(uint2 *frontier, uint32_t *counters, const uint32_t root) {
+    frontier[0] = make_uint2(root, 0u);     // binary root -> wide slot 0
     counters[0] = 1u; counters[1] = 0u; counters[2] = 1u;
 }
 
@@ -261,8 +276,11 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
     const int N = (int)n;
     Box6 *prim = nullptr, *nodeBox = nullptr;
     uint64_t *keys = nullptr, *keysSorted = nullptr;
-    uint32_t *ids = nullptr, *idsSorted = nullptr, *left = nullptr, *right = nullptr, *parI = nullptr, *parL = nullptr, *arrivals = nullptr, *counters = nullptr;
+    uint32_t *ids = nullptr, *idsSorted = nullptr, *left = nullptr, *right = nullptr, *clB = nullptr, *dState = nullptr, *counters = nullptr;
     uint2 *frontier[2] = {nullptr, nullptr};
+    Box6 *cbox[2] = {nullptr, nullptr};
+    uint64_t *flags = nullptr, *scan = nullptr;
+    uint32_t root = 0;
     void *tmp = nullptr; size_t tmpBytes = 0;
     WideNode *wide = nullptr;
     const size_t nInt = (size_t)std::max(N - 1, 1);
@@ -294,17 +312,49 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
     GB_TRY(hipMalloc(&tmp, std::max<size_t>(tmpBytes, 16)));
     GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 64, st));
     GB_TRY(hipMalloc(&left, nInt * 4)); GB_TRY(hipMalloc(&right, nInt * 4));
-    GB_TRY(hipMalloc(&parI, nInt * 4)); GB_TRY(hipMalloc(&parL, (size_t)N * 4));
-    GB_TRY(hipMalloc(&arrivals, nInt * 4));
     GB_TRY(hipMalloc(&nodeBox, nInt * sizeof(Box6)));
     GB_TRY(hipMalloc(&counters, (MAX_LEVELS + 4) * 4));
     GB_TRY(hipMalloc(&frontier[0], nInt * sizeof(uint2))); GB_TRY(hipMalloc(&frontier[1], nInt * sizeof(uint2)));
     GB_TRY(hipMalloc(&wide, nInt * sizeof(WideNode)));
-    GB_TRY(hipMemsetAsync(arrivals, 0, nInt * 4, st));
     GB_TRY(hipMemsetAsync(counters, 0, (MAX_LEVELS + 4) * 4, st));
-    hipLaunchKernelGGL(k_hierarchy, dim3((N - 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, keysSorted, N, left, right, parI, parL);
-    hipLaunchKernelGGL(k_refit, dim3(blocksN), dim3(BLOCK), 0, st, N, left, right, parI, parL, prim, idsSorted, nodeBox, arrivals);
-    hipLaunchKernelGGL(k_seed_frontier, dim3(1), dim3(1), 0, st, frontier[0], counters);
+    {
+        // clusters in Morton order merge with their nearest neighbours until one is left; its node is
+        // the last one made, binary node N - 2
+        GB_TRY(hipMalloc(&clB, (size_t)N * 4));
+        uint32_t *cl[2] = {ids, clB};          // the sort's input ids are free once it has run
+        GB_TRY(hipMalloc(&cbox[0], (size_t)N * sizeof(Box6))); GB_TRY(hipMalloc(&cbox[1], (size_t)N * sizeof(Box6)));
+        GB_TRY(hipMalloc(&flags, (size_t)N * 8)); GB_TRY(hipMalloc(&scan, (size_t)N * 8));
+        GB_TRY(hipMalloc(&dState, 16));         // clusters left, nodes made
+        size_t scanBytes = 0;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, flags, scan, N, st));
+        if (scanBytes > tmpBytes) { hipFree(tmp); tmp = nullptr; tmpBytes = scanBytes; GB_TRY(hipMalloc(&tmp, tmpBytes)); }
+        hipLaunchKernelGGL(k_ploc_init, dim3(blocksN), dim3(BLOCK), 0, st, (uint32_t)N, prim, idsSorted, cl[0], cbox[0]);
+        uint32_t count = (uint32_t)N, made = 0;
+        int radius = PLOC_RADIUS;
+        if (const char *env = getenv("RT_AMD_PLOC_RADIUS")) { const int v = atoi(env); if (v >= 1 && v <= PLOC_RADIUS_MAX) radius = v; }
+        int cur = 0;
+        for (int round = 0; count > 1u; round++) {
+            if (round >= 4096) { err = "GPU index build: clustering did not finish"; rc = RT_E_INVALID; goto done; }
+            const int blocks = (int)((count + BLOCK - 1) / BLOCK);
+            size_t sb = tmpBytes;
+            hipLaunchKernelGGL(k_ploc_nearest, dim3(blocks), dim3(BLOCK), 0, st, count, radius, cbox[cur], (uint32_t *)keys);     // keys is free after the sort: the neighbour choices
+            hipLaunchKernelGGL(k_ploc_flags, dim3(blocks), dim3(BLOCK), 0, st, count, (const uint32_t *)keys, flags);
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, sb, flags, scan, (int)count, st));
+            hipLaunchKernelGGL(k_ploc_merge, dim3(blocks), dim3(BLOCK), 0, st, count, made, (const uint32_t *)keys, flags, scan, cl[cur], cbox[cur],
+                               cl[cur ^ 1], cbox[cur ^ 1], left, right, nodeBox, dState);
+            uint32_t state[2] = {0, 0};
+            GB_TRY(hipMemcpyAsync(state, dState, sizeof state, hipMemcpyDeviceToHost, st));
+            GB_TRY(hipStreamSynchronize(st));
+            if (state[0] >= count || state[0] == 0u || state[1] - made != count - state[0]) {
+                err = "GPU index build: clustering made no progress"; rc = RT_E_INVALID; goto done;
+            }
+            count = state[0]; made = state[1];
+            cur ^= 1;
+        }
+        if (made != (uint32_t)(N - 1)) { err = "GPU index build: clustering left nodes over"; rc = RT_E_INVALID; goto done; }
+        root = (uint32_t)(N - 2);
+    }
+    hipLaunchKernelGGL(k_seed_frontier, dim3(1), dim3(1), 0, st, frontier[0], counters, root);
     for (int level = 0; level < MAX_LEVELS; level++) {
         // level L holds at most 4^L items; the kernel strides over whatever it finds
         const int64_t most = std::min<int64_t>((int64_t)nInt, level < 12 ? ((int64_t)1 << (2 * level)) : (int64_t)nInt);
@@ -318,7 +368,7 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
         uint32_t lastFrontier = 0;
         GB_TRY(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, st));
         GB_TRY(hipMemcpyAsync(&lastFrontier, counters + 2 + MAX_LEVELS, 4, hipMemcpyDeviceToHost, st));
-        GB_TRY(hipMemcpyAsync(&rb, nodeBox, sizeof rb, hipMemcpyDeviceToHost, st));
+        GB_TRY(hipMemcpyAsync(&rb, nodeBox + root, sizeof rb, hipMemcpyDeviceToHost, st));
         GB_TRY(hipStreamSynchronize(st));
         if (lastFrontier != 0u) { err = "GPU index build: tree deeper than the level limit"; rc = RT_E_INVALID; goto done; }
         for (int k = 0; k < 3; k++) { out.rootMin[k] = rb.mn[k]; out.rootMax[k] = rb.mx[k]; }
@@ -329,8 +379,9 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
     out.rootRef = 0u;
 done:
     hipFree(prim); hipFree(nodeBox); hipFree(keys); hipFree(keysSorted); hipFree(ids); hipFree(idsSorted);
-    hipFree(left); hipFree(right); hipFree(parI); hipFree(parL); hipFree(arrivals); hipFree(counters);
+    hipFree(left); hipFree(right); hipFree(clB); hipFree(dState); hipFree(counters);
     hipFree(frontier[0]); hipFree(frontier[1]); hipFree(tmp); hipFree(wide);
+    hipFree(cbox[0]); hipFree(cbox[1]); hipFree(flags); hipFree(scan);
     return rc;
 }
 
