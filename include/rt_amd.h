@@ -124,8 +124,9 @@ typedef struct RtOptions {
                                not affected. */
     int32_t overlap;        /* persistent pipeline only.  1 (default): consecutive batches of frames (calls
                                of rt_render_frames, or the 64-frame batches of one call) alternate between
-                               two internal streams, so that a batch starts while the last paths of the
-                               previous one are still running; accumulation stays in frame order, and the
+                               two internal streams (three for batches of up to ~5M pixel samples, e.g. one
+                               or two 1080p frames per call), so that a batch starts while the last paths
+                               of the previous ones are still running; accumulation stays in frame order, and the
                                context's stream waits for each batch, so reads and the caller's later work
                                on that stream see the result.  Work the CALLER enqueues on the context's
                                stream before a render call is not waited for by the rendering (none of it

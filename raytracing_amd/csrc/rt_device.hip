@@ -734,7 +734,7 @@ static __device__ __align__(256) uint32_t scratch[NOALLOC_SCRATCH_WORDS];
 
 // ====================================================================== host side
 
-constexpr int NSLOT = 2;
+constexpr int NSLOT = 3;
 
 struct RtContext {
     int device = 0;
@@ -797,6 +797,7 @@ struct RtContext {
     int lastSlot = -1;              // slot whose accumulate kernel was enqueued last
     bool inputDirty = false;        // work enqueued on `stream` (reset, restore) that the slots' streams must wait for
     hipEvent_t inputEvent = nullptr;
+    int nSlots = 0;             // launch slots in use (RtOptions.overlap): 0 = by the size of the batch, else 2..NSLOT
     int pathsOcc = 0;           // waves per SIMD the path kernel is compiled for (5, 6 or 7); 0 = by scene size
     int pathsLeafBatch = 8;     // lanes waiting for a triangle pass that trigger one in the path kernel
     WorkCounters *dCounters = nullptr;
@@ -1088,6 +1089,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
         if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
     }
     if (const char *env = getenv("RT_AMD_PATHS_OCC")) ctx->pathsOcc = atoi(env);
+    if (const char *env = getenv("RT_AMD_SLOTS")) { const int v = atoi(env); if (v >= 2 && v <= NSLOT) ctx->nSlots = v; }
     if (const char *env = getenv("RT_AMD_PATHS_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) ctx->pathsLeafBatch = v; }
     if (const char *env = getenv("RT_AMD_ACCEL_LDS_ENTRIES")) {
         const int v = atoi(env);
@@ -1452,8 +1454,13 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             B.nframes = std::min(cap, count - off);
             B.bitsX = bitsX; B.bitsY = bitsY;
             for (int f = 0; f < PATHS_MAX_FRAMES; f++) B.randOrigin[f] = f < B.nframes ? rand_origin[off + f] : 0.0f;
+            // Launch slots: a third one pays for small batches, whose launches are mostly tail (one
+            // frame per call at 1080p +8..20 %, two +2..5 %); from about 5M work items on it costs
+            // (four frames -1..-4 %, eight -6 %, one frame at 4K -1 %): the blocks of two waiting
+            // kernels then share the CUs that come free, and both end later.
+            const int nsl = ctx->nSlots ? ctx->nSlots : ((size_t)B.nframes * ctx->width * ctx->height <= ((size_t)5 << 20) ? 3 : 2);
             const int si = overlap ? ctx->nextSlot : 0;
-            if (overlap) ctx->nextSlot = (si + 1) % NSLOT;
+            if (overlap) ctx->nextSlot = (si + 1) % nsl;
             RtContext::Slot &sl = ctx->slot[si];
             if (fast && !ctx->dAOvf[si]) HIP_TRY(ctx, hipMalloc(&ctx->dAOvf[si], ctx->ovfBytes));
             if (overlap && !sl.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
