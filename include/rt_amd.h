@@ -102,7 +102,8 @@ typedef struct RtSceneInfo {
     int32_t paths_waves_per_simd;   /* variant of the persistent path kernel used for this scene: 5, 6 or 7 */
     int32_t frames_per_launch;      /* most frames one launch of the path kernel renders at this image size */
     int32_t index_built_on_device;  /* 1: the search index of this scene was built on the GPU (RtOptions.index_build) */
-    int32_t reserved;
+    int32_t index_build_fell_back;  /* 1: the device build of the index failed (no working memory, or a tree it
+                                       gives up on) and the host built the index instead */
 } RtSceneInfo;
 
 /* Render options; rt_default_options() gives the reference's behaviour. */
@@ -129,8 +130,10 @@ typedef struct RtOptions {
                                of the previous ones are still running; accumulation stays in frame order, and the
                                context's stream waits for each batch, so reads and the caller's later work
                                on that stream see the result.  Work the CALLER enqueues on the context's
-                               stream before a render call is not waited for by the rendering (none of it
-                               is an input of the rendering).  0: everything runs on the context's stream. */
+                               stream before a render call (a collective on the sum buffer, a memset of a
+                               bound buffer) is waited for by the kernels that add the new frames to the
+                               accumulators, not by the path tracing itself, which reads nothing the caller
+                               can write.  0: everything runs on the context's stream. */
     int32_t index_build;    /* where rt_scene_upload builds the search index of `accel` (read at upload):
                                RT_INDEX_BUILD_HOST: binned SAH on the host (upload of 1.3M triangles in
                                0.3 s, of 10.5M in 2.2 s), the index that traces fastest (by 5 % on those

@@ -679,6 +679,40 @@ void or_render_frame(const OrScene *sc, const OrCamera *cam, float randOrigin,
     }
 }
 
+/* Frames firstLoopNum .. firstLoopNum+count-1 (randOrigin[f] for frame f) over the pixels of
+ * rows y0 <= py < y1: what `count` calls of or_render_frame, each fed the previous one's
+ * output as its history, leave in those rows - the running mean of frag:697 continued from
+ * the contents of `mean` - and the plain fp32 sum of the samples added to `sum` in frame
+ * order.  mean/sum are whole W*H*3 images of which only the band is read and written.
+ * A pixel's frames do not depend on any other pixel, so the loop over pixels is the parallel
+ * one and every thread runs all frames of its pixels: a 16-row band of a thousand frames
+ * keeps all cores busy, which a loop over 16 rows per frame does not. */
+void or_render_band(const OrScene *sc, const OrCamera *cam, int firstLoopNum, int count,
+                    const float *randOrigin, float *mean, float *sum, int y0, int y1) {
+    const int W = sc->width;
+    const long long npix = (long long)(y1 - y0) * W;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long i = 0; i < npix; i++) {
+        const int py = y0 + (int)(i / W), px = (int)(i % W);
+        const size_t o = ((size_t)py * (size_t)W + (size_t)px) * 3;
+        OrCamera c = *cam;
+        float m[3] = {mean[o], mean[o + 1], mean[o + 2]};
+        float s[3] = {sum[o], sum[o + 1], sum[o + 2]};
+        for (int f = 0; f < count; f++) {
+            c.LoopNum = firstLoopNum + f;
+            const float N = (float)c.LoopNum;
+            const float wa = 1.0f / N, wb = (float)(c.LoopNum - 1) / N;
+            float rgb[3];
+            or_shade_pixel(sc, &c, randOrigin[f], px, py, rgb, NULL);
+            for (int k = 0; k < 3; k++) {
+                m[k] = MADD(wa, rgb[k], wb * m[k]);
+                s[k] += rgb[k];
+            }
+        }
+        for (int k = 0; k < 3; k++) { mean[o + k] = m[k]; sum[o + k] = s[k]; }
+    }
+}
+
 /* hitBVH alone (frag:373-456) for traversal parity tests: returns 1 on a hit and gives
  * ray.hitMin (t - 1e-5 of the kept triangle) and that triangle's index. */
 int or_hit_bvh(const OrScene *sc, const float origin[3], const float dir[3], float *t_out, int *tri_out) {

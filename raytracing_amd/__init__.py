@@ -4,7 +4,9 @@ The compute path is the HIP library only: importing this package raises if the l
 missing, and nothing here falls back to a CPU implementation.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -16,6 +18,38 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python raytracing_amd/build.py` "
         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
 
+
+
+def _share_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    librt_amd.so asks the loader for `libamdhip64.so.7`; torch ships a copy of the same runtime
+    in its own lib directory and asks for it as `libamdhip64.so`.  The loader matches a request
+    against the libraries it already holds by file and by soname (`libamdhip64.so.7` in both
+    copies): with torch first, this library binds to torch's copy.  The other way round the
+    loader would map torch's file as a second runtime, and the second one finds no GPU.  So when
+    torch is installed but not loaded yet, its copy is loaded here first; a later `import torch`
+    then finds its own file already mapped.  RT_AMD_HIP_RUNTIME names another file to share."""
+    override = os.environ.get("RT_AMD_HIP_RUNTIME")
+    if override:
+        C.CDLL(override, mode=C.RTLD_GLOBAL)
+        return override
+    if "torch" in sys.modules:
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return cand
+
+
+SHARED_HIP_RUNTIME = _share_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 RT_MAX_SPHERES = 10
@@ -63,7 +97,7 @@ class RtSceneInfo(C.Structure):
     _fields_ = [("triangles", C.c_int64), ("index_nodes", C.c_int64), ("tree_height", C.c_int32),
                 ("index_stack_need", C.c_int32), ("index_stack_lds", C.c_int32), ("index_enabled", C.c_int32),
                 ("paths_waves_per_simd", C.c_int32), ("frames_per_launch", C.c_int32),
-                ("index_built_on_device", C.c_int32), ("reserved", C.c_int32)]
+                ("index_built_on_device", C.c_int32), ("index_build_fell_back", C.c_int32)]
 
 
 class RtOptions(C.Structure):

@@ -1,6 +1,7 @@
 // HIP kernels (gfx950) and the device half of the C ABI declared in include/rt_amd.h.
 // Compile with -ffp-contract=off: every fused multiply-add is written out (rt_math.h).
 #include <hip/hip_runtime.h>
+#include <link.h>
 
 #include <algorithm>
 #include <atomic>
@@ -758,6 +759,7 @@ struct RtContext {
     SceneD scene{};
     bool haveScene = false;
     bool indexOnDevice = false;
+    bool indexFellBack = false;     // the device build of the index failed and the host built it
 
     FrameD frame{};
     bool haveCamera = false;
@@ -830,6 +832,20 @@ hipError_t lookup_scratch(int device) {
     return hipSuccess;
 }
 
+// Paths of the HIP runtime copies mapped into this process, when there is more than one.
+std::string loaded_hip_runtimes() {
+    std::vector<std::string> found;
+    dl_iterate_phdr([](struct dl_phdr_info *info, size_t, void *data) -> int {
+        if (info->dlpi_name && std::strstr(info->dlpi_name, "libamdhip64"))
+            static_cast<std::vector<std::string> *>(data)->push_back(info->dlpi_name);
+        return 0;
+    }, &found);
+    if (found.size() < 2) return std::string();
+    std::string out;
+    for (const auto &f : found) out += (out.empty() ? "" : ", ") + f;
+    return out;
+}
+
 int fail(RtContext *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
     rt::set_global_error(msg);
@@ -855,16 +871,26 @@ hipEvent_t take_event(RtContext *ctx) {
     return e;
 }
 
+void give_back_events(RtContext *ctx, hipEvent_t a, hipEvent_t b) {
+    if (a) ctx->freeEvents.push_back(a);
+    if (b) ctx->freeEvents.push_back(b);
+}
+
 int resolve_events(RtContext *ctx) {
+    int rc = RT_OK;
     for (auto &pr : ctx->pendingEvents) {
-        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        // a pair that a failed render call left half recorded has no time to give
         float ms = 0.0f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
-        ctx->kernelMs += (double)ms; ctx->kernelLaunches++;
+        hipError_t e = hipEventSynchronize(pr.second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
+        if (e == hipSuccess) { ctx->kernelMs += (double)ms; ctx->kernelLaunches++; }
+        else if (e != hipErrorInvalidHandle && e != hipErrorInvalidResourceHandle && e != hipErrorNotReady)
+            rc = fail(ctx, RT_E_HIP, std::string("rt_amd: kernel timing: ") + hipGetErrorString(e));
+        else (void)hipGetLastError();
         ctx->freeEvents.push_back(pr.first); ctx->freeEvents.push_back(pr.second);
     }
     ctx->pendingEvents.clear();
-    return RT_OK;
+    return rc;
 }
 
 // fn(begin, end) over [0, n) on up to 16 host threads (the upload's per-record conversions).
@@ -881,6 +907,14 @@ void parallel_for(int64_t n, Fn fn) {
         pool.emplace_back([=] { fn(b, e); });
     }
     for (auto &th : pool) th.join();
+}
+
+// Waits for everything this context has in flight: its own stream and the launch slots' streams.
+hipError_t sync_all_streams(RtContext *ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    for (auto &sl : ctx->slot)
+        if (sl.stream) { const hipError_t e2 = hipStreamSynchronize(sl.stream); if (e == hipSuccess) e = e2; }
+    return e;
 }
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1050,8 +1084,17 @@ int rt_create(RtContext **out, int width, int height, int device) {
     if (width <= 0 || height <= 0 || width > 16384 || height > 16384)
         return fail(nullptr, RT_E_INVALID, "rt_create: width/height must be in 1..16384");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        // A process that holds two copies of the HIP runtime (an application that bundles its own,
+        // loaded after this library bound to the system's) shows exactly this: the second copy
+        // sees no GPU.  Say so instead of "no device".
+        const std::string copies = loaded_hip_runtimes();
+        if (!copies.empty())
+            return fail(nullptr, RT_E_HIP, "rt_create: no HIP device visible, and this process holds more than one HIP runtime (" + copies +
+                        "): load the runtime the application bundles before librt_amd.so, so that both use one copy");
         return fail(nullptr, RT_E_HIP, "rt_create: no HIP device available (this library has no CPU path)");
+    }
     if (device < 0 || device >= ndev) return fail(nullptr, RT_E_INVALID, "rt_create: device index out of range");
     RtContext *ctx = new (std::nothrow) RtContext;
     if (!ctx) return fail(nullptr, RT_E_NOMEM, "rt_create: out of memory");
@@ -1114,7 +1157,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
 void rt_destroy(RtContext *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)sync_all_streams(ctx);        // a failed render call may have left kernels on a slot's stream that the context's stream never waited for
     for (auto &pr : ctx->pendingEvents) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->freeEvents) hipEventDestroy(e);
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dVNrm);
@@ -1136,9 +1179,7 @@ void rt_destroy(RtContext *ctx) {
 int rt_set_stream(RtContext *ctx, void *hip_stream) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_set_stream: null context");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &sl : ctx->slot)
-        if (sl.stream) HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+    HIP_TRY(ctx, sync_all_streams(ctx));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->inputDirty = true;
     return RT_OK;
@@ -1184,7 +1225,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     };
     if (wantIndex && !gpuBuild) host_build();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all_streams(ctx));
     hipFree(ctx->dNodes); hipFree(ctx->dTris); hipFree(ctx->dMats); hipFree(ctx->dANodes); hipFree(ctx->dVNrm); hipFree(ctx->dUVs);
     ctx->dVNrm = nullptr; ctx->dUVs = nullptr;
     for (auto &p : ctx->dAOvf) { hipFree(p); p = nullptr; }
@@ -1226,15 +1267,21 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
     uint32_t indexNodes = 0; int indexStackNeed = 0;
     rt::GpuIndex gi;
     bool haveGpuIndex = false;
+    bool indexFellBack = false;
     if (gpuBuild) {
         std::string gerr;
-        const int grc = rt::build_index_gpu(ctx->dTris, n, S.rootMin, S.rootMax, S.cullEps * 1024.0f, ctx->stream, gi, gerr);
+        int grc;
+        if (getenv("RT_AMD_TEST_FAIL_GPU_INDEX")) { grc = RT_E_NOMEM; gerr = "GPU index build: failure requested by RT_AMD_TEST_FAIL_GPU_INDEX"; }   // test hook
+        else grc = rt::build_index_gpu(ctx->dTris, n, S.rootMin, S.rootMax, S.cullEps * 1024.0f, ctx->stream, gi, gerr);
         if (grc == RT_OK) haveGpuIndex = true;
-        else if (ctx->opt.index_build == RT_INDEX_BUILD_GPU) return fail(ctx, grc, "rt_scene_upload: " + gerr);
-        else {      // automatic choice: the device build did not get its working memory; build on the host instead
+        else {
+            // The device build did not get its working memory (about 236 bytes per triangle) or gave
+            // up on the tree's shape: the host builds the index instead, whichever mode asked for the
+            // device build.  A HIP error that stays is reported by the calls that follow.
             if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "rt_amd: device index build failed (%s), building on the host\n", gerr.c_str());
             (void)hipGetLastError();
             gpuBuild = false;
+            indexFellBack = true;
             host_build();
         }
     }
@@ -1289,6 +1336,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
                 tConverted - tStart, now_ms() - tConverted);
     ctx->nIndexNodes = haveAccel ? (int64_t)indexNodes : 0;
     ctx->indexOnDevice = haveAccel && gpuBuild;
+    ctx->indexFellBack = indexFellBack;
     ctx->indexStackNeed = haveAccel ? indexStackNeed : 0;
     return RT_OK;
 }
@@ -1322,9 +1370,7 @@ int rt_set_albedo_texture(RtContext *ctx, const uint8_t *rgb, int width, int hei
         return fail(ctx, RT_E_INVALID, "rt_set_albedo_texture: width/height must be in 1..16384");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // kernels of earlier render calls may still read the old image
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto &sl : ctx->slot)
-        if (sl.stream) HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+    HIP_TRY(ctx, sync_all_streams(ctx));
     hipFree(ctx->dTexels); ctx->dTexels = nullptr; ctx->texW = ctx->texH = 0;
     if (!rgb) return RT_OK;
     const size_t bytes = (size_t)width * (size_t)height * 3;
@@ -1416,7 +1462,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dRandOrigin, rand_origin, (size_t)count * sizeof(float), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
-        if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
+        if (!e0 || !e1) { give_back_events(ctx, e0, e1); return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed"); }
+        ctx->pendingEvents.emplace_back(e0, e1);
         HIP_TRY(ctx, hipEventRecord(e0, st));
 #define LAUNCH_MEGA(C, N) hipLaunchKernelGGL((k_megakernel<C, N>), dim3(tileBlocks), dim3(BLOCK), lds, st, S, F, first_loopnum, count, ctx->dRandOrigin, ctx->dSobolV, ctx->dSum, ctx->dMean, ctx->opt.history8, ctx->dCounters)
         if (ext) {     // shading extensions: the counting instantiations only
@@ -1428,8 +1475,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
 #undef LAUNCH_MEGA
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(e1, st));
-        ctx->pendingEvents.emplace_back(e0, e1);
         ctx->frames += (uint64_t)count;
+        ctx->inputDirty = true;         // the accumulators were written on the context's stream
         return RT_OK;
     }
 
@@ -1447,7 +1494,22 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         const int occ = ext ? 5 : paths_occupancy(ctx);
         const int blocks = ctx->numCU * (fast ? occ : 5) * (BLOCK / PATHS_BLOCK);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
-        if (overlap && !ctx->inputEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->inputEvent, hipEventDisableTiming));
+        if (overlap) {
+            // Everything enqueued on the context's stream before this call - by the caller (a collective
+            // on the sum buffer, a memset of it) or by this library (a reset, another pipeline's frames,
+            // rt_trace_rays_noalloc, which shares slot 0's overflow columns) - is marked here.  The
+            // accumulate kernels of this call always wait for the mark: they are the only kernels
+            // that touch memory the caller can see (the sum buffer may be the caller's).  The path
+            // kernels wait for it only when the library itself put work there (inputDirty); making
+            // them wait every time would serialise the batches, since the context's stream waits for
+            // every batch's accumulate kernel.
+            if (!ctx->inputEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->inputEvent, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ctx->inputEvent, st));
+            if (ctx->inputDirty) {
+                for (auto &o : ctx->slot)
+                    if (o.stream) HIP_TRY(ctx, hipStreamWaitEvent(o.stream, ctx->inputEvent, 0));
+            }
+        }
         for (int off = 0; off < count; off += cap) {
             BatchD B;
             B.firstLoopNum = first_loopnum + off;
@@ -1475,12 +1537,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             if (!sl.dWorkHead) HIP_TRY(ctx, hipMalloc(&sl.dWorkHead, 128));
             if (!sl.dSobTable) HIP_TRY(ctx, hipMalloc(&sl.dSobTable, (size_t)PATHS_MAX_FRAMES * RT_MAX_BOUNCES * 2 * sizeof(float)));
             if (overlap && ctx->inputDirty) {
-                // what this library put on the context's stream since the last batch (clearing or
-                // restoring the accumulators) comes first on both slots' streams
-                HIP_TRY(ctx, hipEventRecord(ctx->inputEvent, st));
-                for (auto &o : ctx->slot)
-                    if (o.stream) HIP_TRY(ctx, hipStreamWaitEvent(o.stream, ctx->inputEvent, 0));
-                ctx->inputDirty = false;
+                // a slot whose stream was only created just now (above) has not seen the mark yet
+                HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->inputEvent, 0));
             }
             SceneD Sp = S;
             Sp.leafBatch = ctx->pathsLeafBatch;
@@ -1490,7 +1548,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, ps, B, F.maxBounces, ctx->dSobolV, sl.dSobTable);
             HIP_TRY(ctx, hipMemsetAsync(sl.dWorkHead, 0, sizeof(uint32_t), ps));
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
-            if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
+            if (!e0 || !e1) { give_back_events(ctx, e0, e1); return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed"); }
+            ctx->pendingEvents.emplace_back(e0, e1);    // owned by the context from here on, whatever fails below
             HIP_TRY(ctx, hipEventRecord(e0, ps));
 #define LAUNCH_PATHS(A, C, N, O) hipLaunchKernelGGL((k_paths<A, C, N, O>), dim3(blocks), dim3(PATHS_BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
 #define LAUNCH_PATHS_VN(A, C) hipLaunchKernelGGL((k_paths<A, C, true, 5, true>), dim3(blocks), dim3(PATHS_BLOCK), ldsP, ps, Sp, F, B, sl.dSobTable, sl.dWorkHead, sl.dCurBatch, ctx->dCounters)
@@ -1509,10 +1568,11 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
 #undef LAUNCH_PATHS
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(e1, ps));
-            ctx->pendingEvents.emplace_back(e0, e1);
-            // the running mean is folded in frame order: after the previous batch's accumulate kernel
+            // the running mean is folded in frame order: after the previous batch's accumulate kernel,
+            // and after whatever was on the context's stream when the call began
             if (overlap && ctx->lastSlot >= 0 && ctx->lastSlot != si)
                 HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->slot[ctx->lastSlot].accDone, 0));
+            if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->inputEvent, 0));
             hipLaunchKernelGGL(k_accumulate_batch, dim3(accBlocks), dim3(BLOCK), 0, ps, sl.dCurBatch, ctx->dSum, ctx->dMean, nfloats,
                                B.firstLoopNum, B.nframes, ctx->opt.history8);
             HIP_TRY(ctx, hipGetLastError());
@@ -1524,6 +1584,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             }
         }
         ctx->frames += (uint64_t)count;
+        // overlapped: the slots have seen the mark; otherwise this call itself worked on the context's stream
+        ctx->inputDirty = !overlap;
         return RT_OK;
     }
 
@@ -1537,6 +1599,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     const int qstride = NSHARD * CTL_STRIDE;
     const bool useAccel = ctx->opt.accel != 0 && S.anodes != nullptr;
     const size_t ldsFast = fast_stack_bytes(ctx);
+    ctx->inputDirty = true;             // accumulators and slot 0's overflow columns are used on the context's stream
     for (int f = 0; f < count; f++) {
         const int loopNum = first_loopnum + f;
         HIP_TRY(ctx, hipMemsetAsync(ctx->dQueueCtl, 0, QCTL_WORDS * sizeof(uint32_t), st));
@@ -1544,7 +1607,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         for (int b = 0; b < F.maxBounces; b++) {
             const PathSoA &qin = ctx->q[b & 1], &qout = ctx->q[(b + 1) & 1];
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
-            if (!e0 || !e1) return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed");
+            if (!e0 || !e1) { give_back_events(ctx, e0, e1); return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed"); }
+            ctx->pendingEvents.emplace_back(e0, e1);
             HIP_TRY(ctx, hipEventRecord(e0, st));
             if (useAccel) {
                 if (cnt) hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
@@ -1556,7 +1620,6 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
 #undef LAUNCH_EXT
             }
             HIP_TRY(ctx, hipEventRecord(e1, st));
-            ctx->pendingEvents.emplace_back(e0, e1);
             if (ext) hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
                                          ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
             else hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
@@ -1638,6 +1701,7 @@ int rt_get_scene_info(RtContext *ctx, RtSceneInfo *out) {
     out->paths_waves_per_simd = (ctx->opt.accel != 0 && ctx->scene.anodes) ? paths_occupancy(ctx) : 5;
     out->frames_per_launch = paths_frames_cap(ctx);
     out->index_built_on_device = ctx->indexOnDevice ? 1 : 0;
+    out->index_build_fell_back = ctx->indexFellBack ? 1 : 0;
     return RT_OK;
 }
 
@@ -1758,6 +1822,9 @@ int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d
     }
     hipLaunchKernelGGL(k_unstage_hits, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, hitT, hitTri, (uint32_t)n, d_t_out, d_id_out);
     HIP_TRY(ctx, hipGetLastError());
+    // the extend kernel keeps the stack of an exact re-trace in slot 0's overflow columns: the next
+    // overlapped batch on that slot has to come after it
+    ctx->inputDirty = true;
     return RT_OK;
 }
 

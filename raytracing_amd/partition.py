@@ -22,8 +22,9 @@ def rand_origin_stream(seed, total_frames):
 
 
 def reduce_sum_to_root(sum_tensor, dist=None):
-    """Sum-reduce the per-rank W*H*3 fp32 sums to rank 0 (RCCL over xGMI on GPUs, gloo on CPU)."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    """Sum-reduce the per-rank W*H*3 fp32 sums to rank 0 (RCCL over xGMI on GPUs, gloo on CPU).
+    A group of one rank still goes through the backend (the collective is then a copy in place)."""
+    if dist is not None and dist.is_initialized():
         dist.reduce(sum_tensor, dst=0, op=dist.ReduceOp.SUM)
     return sum_tensor
 

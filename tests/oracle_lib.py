@@ -92,6 +92,8 @@ def load(fused=True):
     lib.or_shade_pixel.argtypes = [C.POINTER(OrScene), C.POINTER(OrCamera), C.c_float, i, i, vp, vp]
     lib.or_render_frame.restype = None
     lib.or_render_frame.argtypes = [C.POINTER(OrScene), C.POINTER(OrCamera), C.c_float, vp, vp, vp, i, i, vp]
+    lib.or_render_band.restype = None
+    lib.or_render_band.argtypes = [C.POINTER(OrScene), C.POINTER(OrCamera), i, i, vp, vp, vp, i, i]
     lib.or_hit_bvh.restype = i
     lib.or_hit_bvh.argtypes = [C.POINTER(OrScene), vp, vp, C.POINTER(C.c_float), C.POINTER(i)]
     lib.or_hit_bvh_many.restype = None
@@ -211,6 +213,21 @@ class OracleScene:
             if st:
                 total = st if total is None else {a: total[a] + st[a] for a in st}
         return hist, total
+
+    def render_band(self, cam_np, first_loopnum, rand_origins, rows, mean=None, total=None):
+        """Frames first_loopnum.. over rows [y0, y1): (running mean, plain sum) of those rows, each
+        (y1 - y0, W, 3); `mean` / `total` continue earlier bands of the same rows."""
+        y0, y1 = rows
+        m = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        s = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        if mean is not None:
+            m[y0:y1] = mean
+        if total is not None:
+            s[y0:y1] = total
+        ro = np.ascontiguousarray(rand_origins, dtype=np.float32)
+        cam = self.camera(cam_np, first_loopnum)
+        self.lib.or_render_band(C.byref(self.s), C.byref(cam), first_loopnum, ro.shape[0], _ptr(ro), _ptr(m), _ptr(s), y0, y1)
+        return m[y0:y1].copy(), s[y0:y1].copy()
 
     def hit_bvh(self, origins, dirs):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -1,0 +1,138 @@
+"""Stream ordering of the overlapped launch slots (RtOptions.overlap).
+
+The path kernels of consecutive batches run on internal streams; what they share with work on the
+context's stream - the accumulators, the sum buffer a caller may own, slot 0's overflow columns
+(also the stack of rt_trace_rays_noalloc's exact re-trace) - has to be ordered by events, not by
+luck.  Every case here enqueues without synchronising in between and compares with the result of
+the same steps done one at a time."""
+import numpy as np
+import pytest
+
+import raytracing_amd as rt
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+W, H = 160, 96
+
+
+def _hall():
+    sc = rt.Scene()
+    sc.push_synthetic(1, 6, 1, 12345)                       # column hall: diffuse / mirror / glass + two spheres
+    return sc
+
+
+def _eq(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def test_noalloc_trace_followed_by_render_without_synchronising():
+    """rt_trace_rays_noalloc keeps the stack of its exact re-traces in the overflow columns that
+    slot 0's path kernel uses; axis-parallel rays and rays from far away are re-traced by design."""
+    import torch
+    sc = _hall()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    r.set_spheres(sc.spheres())
+    r.set_camera(rt.camera_default(W, H))
+    n = 200000
+    o, d = scenes.random_rays(n, 41, extent=12.0, axis_aligned_fraction=0.5)
+    o[n // 2:] *= np.float32(40.0)                          # far outside: the index hands these to the exact path
+    t_want, id_want = r.trace_rays(o, d)
+    ro = rt.rand_origins(9, 24)
+    r.reset()
+    r.render(1, ro)
+    want_img = r.read_mean()
+    do, dd = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    dt = torch.zeros(n, dtype=torch.float32, device="cuda")
+    di = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        r.reset()
+        r.trace_rays_noalloc(do.data_ptr(), dd.data_ptr(), n, dt.data_ptr(), di.data_ptr())
+        for k in range(0, 24, 4):                           # slots 0, 1, 2, 0, ... start right behind the trace
+            r.render(k + 1, ro[k:k + 4])
+        r.trace_rays_noalloc(do.data_ptr(), dd.data_ptr(), n, dt.data_ptr(), di.data_ptr())
+        r.synchronize()
+        assert _eq(r.read_mean(), want_img)
+        assert np.array_equal(di.cpu().numpy(), id_want) and np.array_equal(dt.cpu().numpy(), t_want)
+    r.close()
+
+
+def test_pipeline_and_overlap_switches_without_reset():
+    """Frames 1..24 rendered in six runs of four by six different configurations, one after the
+    other with no reset or synchronisation: megakernel, overlapped paths, wavefront, paths on the
+    context's stream, overlapped paths one frame per call, wavefront in reference order.  Every
+    configuration gives the oracle's samples bit for bit, so the running mean must equal that of
+    one call."""
+    sc = _hall()
+    r = rt.make_renderer(sc, W, H)
+    ro = rt.rand_origins(77, 24)
+    r.render(1, ro)
+    want = (r.read_mean(), r.read_sum(), r.stats()["rays"])
+    runs = [dict(pipeline=rt.PIPELINE_MEGAKERNEL), dict(pipeline=rt.PIPELINE_PERSISTENT, overlap=True),
+            dict(pipeline=rt.PIPELINE_WAVEFRONT), dict(pipeline=rt.PIPELINE_PERSISTENT, overlap=False),
+            dict(pipeline=rt.PIPELINE_PERSISTENT, overlap=True), dict(pipeline=rt.PIPELINE_WAVEFRONT, accel=False)]
+    for rep in range(2):
+        r.reset()
+        for k, opts in enumerate(runs):
+            r.set_options(**opts)
+            if k == 4:
+                for f in range(4):
+                    r.render(4 * k + f + 1, ro[4 * k + f:4 * k + f + 1])
+            else:
+                r.render(4 * k + 1, ro[4 * k:4 * k + 4])
+        got = (r.read_mean(), r.read_sum(), r.stats()["rays"])
+        assert _eq(got[0], want[0]) and _eq(got[1], want[1]) and got[2] == want[2]
+    r.close()
+
+
+def test_caller_work_on_the_context_stream_comes_before_the_accumulation():
+    """A caller that owns the sum buffer (rt_bind_sum_buffer) clears it on the context's stream
+    between two render calls, behind a kernel that keeps that stream busy for a while: the second
+    call's frames must be added after the clearing, not before."""
+    import torch
+    if not hasattr(torch.cuda, "_sleep"):
+        pytest.skip("torch.cuda._sleep is not available")
+    sc = _hall()
+    r = rt.make_renderer(sc, W, H)
+    ro = rt.rand_origins(5, 16)
+    r.render(9, ro[8:])
+    want = r.read_sum()
+    stream = torch.cuda.Stream()
+    r.set_stream(stream.cuda_stream)
+    sum_t = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    r.bind_sum_buffer(sum_t.data_ptr())
+    for _ in range(3):
+        r.reset()
+        r.render(1, ro[:8])
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(200_000_000)                  # tens of milliseconds on the context's stream
+            sum_t.zero_()
+        r.render(9, ro[8:])                                 # a few hundred microseconds of path tracing
+        r.synchronize()
+        got = sum_t.cpu().numpy().reshape(H, W, 3)
+        assert _eq(got, want)
+    r.bind_sum_buffer(0)
+    r.set_stream(0)
+    r.close()
+
+
+def test_explicit_gpu_index_build_falls_back_to_the_host(monkeypatch):
+    """RT_INDEX_BUILD_GPU whose build gives up (here: forced through the test hook) must leave a
+    working scene with a host-built index, as the automatic mode does."""
+    monkeypatch.setenv("RT_AMD_TEST_FAIL_GPU_INDEX", "1")
+    sc = _hall()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    r = rt.Renderer(W, H)
+    r.set_options(index_build=rt.INDEX_BUILD_GPU)
+    r.upload(tris, nodes)
+    info = r.scene_info()
+    assert info["index_enabled"] == 1 and info["index_built_on_device"] == 0 and info["index_build_fell_back"] == 1
+    monkeypatch.delenv("RT_AMD_TEST_FAIL_GPU_INDEX")
+    r.upload(tris, nodes)
+    info = r.scene_info()
+    assert info["index_built_on_device"] == 1 and info["index_build_fell_back"] == 0
+    r.close()
