@@ -57,7 +57,13 @@ def cpu_baseline(rt, tris, nodes, spheres, cam, W, H, bounces, ro, budget_s=15.0
     of frame 1 of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    threads = min(16, os.cpu_count() or 1)
+    nproc = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = nproc
+    # the share of the host that belongs to one GPU (16 cores on the 8-GPU nodes this runs on)
+    threads = min(16, usable)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     osc = ol.scene_from_build(tris, nodes, W, H, rt.sobol_default_table(), spheres, max_bounces=bounces)
     # whole frames 1, 2, ... until about budget_s of CPU time has been spent (at least one frame)
@@ -67,9 +73,21 @@ def cpu_baseline(rt, tris, nodes, spheres, cam, W, H, bounces, ro, budget_s=15.0
         rays += st["rays"]
         frames += 1
     dt = time.time() - t0
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gl_probe
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "host_nproc": nproc, "host_cpus_usable": usable,
             "sample": f"frames 1..{frames} of the same workload at full resolution ({rays} rays, {dt:.1f} s), "
-                      "oracle/rt_oracle.c with OpenMP over rows; no hitMin culling, re-traces excluded from the count"}
+                      "oracle/rt_oracle.c with OpenMP over rows; no hitMin culling, re-traces excluded from the count",
+            # the context baseline the reference's shader under Mesa llvmpipe would give: only possible where a
+            # GL context can be created without a display
+            "llvmpipe": gl_probe.probe()}
+
+
+def frames_per_launch(frames_per_call, cap):
+    """rt_render_frames cuts a call into launches of equal size, none above the most a launch holds."""
+    n = -(-frames_per_call // cap)
+    return -(-frames_per_call // n)
 
 
 def call_granularity(r, ro, opts, frames=64):
@@ -82,17 +100,25 @@ def call_granularity(r, ro, opts, frames=64):
     if frames < 8:
         return out
     r.set_options(count_work=False, **opts)
-    for per_call in (1, 8):
+    # (frames per call, what follows every call): nothing = calls pipelined on the GPU; "read_mean" = the
+    # reference's loop, which displays the image after every frame (main.cpp:178-197: a blocking
+    # device-to-host copy of W*H*3 floats here); "synchronize" = the same wait without the copy
+    for per_call, after in ((1, None), (8, None), (1, "synchronize"), (1, "read_mean")):
         for timed in (False, True):                         # one untimed pass first
             r.reset()
             r.synchronize()
             t0 = time.perf_counter()
             for first in range(1, frames + 1, per_call):
                 r.render(first, ro[first - 1:first - 1 + per_call])
+                if after == "read_mean":
+                    r.read_mean()
+                elif after == "synchronize":
+                    r.synchronize()
             r.synchronize()
             dt = time.perf_counter() - t0
         rays = r.stats()["rays"]
-        out.append({"frames_per_call": per_call, "calls": frames // per_call, "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+        out.append({"frames_per_call": per_call, "after_each_call": after or "nothing (pipelined)", "calls": frames // per_call,
+                    "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
                     "ms_per_call": round(dt / (frames // per_call) * 1e3, 4)})
     return out
 
@@ -100,12 +126,13 @@ def call_granularity(r, ro, opts, frames=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 10; 8 for sponza, whose 8 x 64 frames are one GPU's "
+                    "share of the 4096 samples that configuration splits over 8 GPUs)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon1m", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=0,
-                    help="frames per step (default: 64, or the largest multiple of the workload's frames per launch "
-                         "below that: 63 at 4K, where a launch holds 21 frames)")
+                    help="frames per step (default 64; where a launch holds fewer, e.g. 21 at 4K, the call is cut "
+                         "into launches of equal size)")
     ap.add_argument("--pipeline", default="persistent", choices=["wavefront", "megakernel", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
@@ -132,6 +159,10 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
+    if world > 1 and "RT_AMD_HOST_THREADS" not in os.environ:
+        # every rank builds its own tree and search index on the host before the timed region:
+        # share the host's cores between the ranks instead of 16 threads each
+        os.environ["RT_AMD_HOST_THREADS"] = str(max(2, min(16, (os.cpu_count() or 16) // world)))
     import torch
     import raytracing_amd as rt
     from raytracing_amd import partition
@@ -171,9 +202,11 @@ def main():
     info = r.scene_info()
 
     F, K, Wm = args.spp_per_step, args.steps, args.warmup
+    if K <= 0:
+        # sponza is stated at 4096 samples over 8 GPUs: 512 per GPU = 8 steps of 64; the others take 10 steps
+        K = 8 if args.workload == "sponza" else 10
     if F <= 0:
-        cap = info["frames_per_launch"]
-        F = 64 if cap >= 64 else max(cap, 64 // cap * cap)
+        F = 64
     if args.total_spp:
         if args.total_spp % (world * K):
             raise SystemExit("--total-spp must be divisible by gpus * steps")
@@ -249,19 +282,33 @@ def main():
         flops_per_ray = (21.0 * w["node_tests"] + 95.0 * w["tri_tests"]) / rays_w + 150.0
         valu_tflops = flops_per_ray * rays_local / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         # Counters of the dominant kernel from the committed PMC passes of the same workload
-        # (profiles/r02_pmc_<workload>.json, made by tools/pmc_to_json.py): traffic beyond L2,
-        # vector issue rate and lane utilisation.  Only used when they describe this configuration.
+        # (profiles/r0N_pmc_<workload>.json, made by tools/pmc_to_json.py; the newest round that has one):
+        # traffic beyond L2, vector issue rate and lane utilisation.  They are NOT measured in this run
+        # (counter collection needs rocprofv3 around the process) and are only used when they
+        # describe this configuration; every such field sits in `pmc` with from_committed_profile.
+        fpl = frames_per_launch(F, info["frames_per_launch"])
         traffic = None
         pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
-        try:
-            cand = json.load(open(pmc_path))
-            if (cand["workload"] == args.workload and not args.no_accel and args.pipeline == cand["pipeline"]
-                    and min(F, info["frames_per_launch"]) == cand["frames_per_dispatch"] and not args.resolution):
-                pmc = cand
-                traffic = round((pmc["fetch_size_kb_per_dispatch"] * pmc["fetch_correction"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
-        except (OSError, KeyError, ValueError):
-            pmc = None
+        pmc_path = None
+        for rnd in ("r03", "r02"):
+            cand_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.workload}.json")
+            try:
+                cand = json.load(open(cand_path))
+                if (cand["workload"] == args.workload and not args.no_accel and args.pipeline == cand["pipeline"]
+                        and fpl == cand["frames_per_dispatch"] and not args.resolution):
+                    pmc, pmc_path = cand, cand_path
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
+        traffic_lo = traffic_hi = None
+        if pmc:
+            # FETCH_SIZE counts requests of 32 or 64 bytes in one unit; x2 is right for wide coalesced
+            # reads (all 64-byte requests), x1 for 32-byte ones.  The divergent 16-byte gathers of a
+            # traversal lie between the two, so the traffic is a range; `traffic` is its upper end.
+            traffic_lo = round((pmc["fetch_size_kb_per_dispatch"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
+            traffic_hi = round((pmc["fetch_size_kb_per_dispatch"] * pmc["fetch_correction"] + pmc["write_size_kb_per_dispatch"]) * 1024.0)
+            traffic = traffic_hi
+        launch_s = kernel_ms * 1e-3 / max(launches, 1)
         dominant = {rt.PIPELINE_WAVEFRONT: "k_extend" if args.no_accel else "k_extend_fast",
                     rt.PIPELINE_MEGAKERNEL: "k_megakernel", rt.PIPELINE_PERSISTENT: "k_paths"}[pipeline]
         result = {
@@ -273,7 +320,7 @@ def main():
             "config": {"workload": f"{args.workload}: {desc} (BASELINE.json configs[{cfg_idx}])",
                        "triangles": int(tris.shape[0]), "bvh_nodes": int(nodes.shape[0]),
                        "resolution": f"{W}x{H}", "spp_per_step": F, "frames_per_call": F,
-                       "frames_per_launch": min(F, info["frames_per_launch"]), "total_spp": K * world * F, "max_bounces": bounces,
+                       "frames_per_launch": fpl, "total_spp": K * world * F, "max_bounces": bounces,
                        "pipeline": args.pipeline, "cull": not args.no_cull, "search_index": not args.no_accel,
                        "parallelism": f"spp-partition x{world}, one RCCL sum-reduce" if world > 1 else "single GPU",
                        "rays_per_step_per_gpu": round(rays_local / K, 1), "bvh_build_s": round(bvh_s, 2),
@@ -284,9 +331,12 @@ def main():
             # binds is the fp32 vector unit, not HBM: `achieved` is the algorithmic fp32 work (21 flop
             # per box tested, 95 per triangle tested, 150 per ray shaded) over the kernel's time.
             "roofline": {"bound": "valu", "kernel": dominant, "achieved": round(valu_tflops, 3), "peak": VALU_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch beyond L2 (PMC FETCH_SIZE x2 + WRITE_SIZE; includes Infinity Cache hits)",
-                         "traffic_source": os.path.relpath(pmc_path, ROOT) if pmc else None,
+                         "unit": "TFLOP/s", "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
+                         # the same algorithmic work over the wall time of the timed region (all kernels, launch
+                         # gaps and the overlap of consecutive launches included)
+                         "frac_on_wall": round(flops_per_ray * rays_local / elapsed / 1e12 / VALU_PEAK_TFLOPS, 4),
+                         "traffic": traffic,
+                         "traffic_unit": "bytes per launch beyond L2, upper end of traffic_range (includes Infinity Cache hits)",
                          "flops_per_ray": round(flops_per_ray, 1),
                          "kernel_ms_per_launch": round(kernel_ms / max(launches, 1), 4), "launches": launches,
                          "kernel_share_of_wall": round(kernel_ms * 1e-3 / elapsed, 3),
@@ -298,15 +348,20 @@ def main():
                          "bytes_per_ray_at_32B_per_box": round(binary_bpr, 1),
                          "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_local / max(launches, 1)),
                          "cache_served_tbps": round(achieved / 1e3, 3),
-                         "hbm_frac": (round(traffic / (kernel_ms * min(F, info["frames_per_launch"]) / (K * F) * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
-                                      if traffic and kernel_ms > 0 else None),
-                         "hbm_note": "hbm_frac = PMC traffic beyond L2 per full launch / time of a full launch / 8 TB/s: an upper bound on the "
-                                     "HBM share, Infinity Cache hits are counted in it",
                          "timing_note": "kernel_ms_per_launch is the HIP-event time of each launch on its own stream; with overlap the end of "
-                                        "one launch and the start of the next share the GPU, so the sum can exceed the wall time",
-                         "valu_issue_frac": pmc.get("valu_issue_frac_of_guide_peak") if pmc else None,
-                         "valu_lane_utilisation": pmc.get("valu_lane_utilisation") if pmc else None,
-                         "l2_hit_rate": pmc.get("l2_hit_rate") if pmc else None},
+                                        "one launch and the start of the next share the GPU, so the sum can exceed the wall time "
+                                        "(kernel_share_of_wall > 1); frac_on_wall is the self-consistent figure",
+                         "pmc": ({"from_committed_profile": True, "source": os.path.relpath(pmc_path, ROOT),
+                                  "traffic_range": [traffic_lo, traffic_hi],
+                                  "traffic_range_note": "PMC FETCH_SIZE x1 .. x2 + WRITE_SIZE per launch: x2 holds for coalesced 64-byte "
+                                                        "requests, divergent 16-byte gathers lie in between",
+                                  "hbm_frac_range": [round(traffic_lo / launch_s / (HBM_PEAK_GBS * 1e9), 4),
+                                                     round(traffic_hi / launch_s / (HBM_PEAK_GBS * 1e9), 4)] if launch_s > 0 else None,
+                                  "hbm_note": "traffic beyond L2 per launch / this run's time per launch / 8 TB/s: an upper bound on the "
+                                              "HBM share, Infinity Cache hits are counted in it",
+                                  "valu_issue_frac": pmc.get("valu_issue_frac_of_guide_peak"),
+                                  "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
+                                  "l2_hit_rate": pmc.get("l2_hit_rate")} if pmc else None)},
         }
         if world == 1 and not args.no_call_granularity and pipeline == rt.PIPELINE_PERSISTENT:
             result["call_granularity"] = call_granularity(r, ro, opts)

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "rt_accel.h"
+#include "rt_internal.h"
 
 namespace rt {
 
@@ -83,7 +84,7 @@ struct Builder {
     // split off while it is the small part (at most a tenth of the range).
     uint32_t build_by_size(int64_t begin, int64_t end, Box &box, float sceneExtent, int cls) {
         const int64_t count = end - begin;
-        if (cls >= 3 || count < 64) return build(begin, end, box, 4);
+        if (cls >= 3 || count < 64) return build(begin, end, box, host_fork_levels());
         const float thr = sceneExtent * (cls == 0 ? 0.25f : (cls == 1 ? 0.0625f : 0.015625f));
         Prim *first = prims + begin, *last = prims + end;
         Prim *m = std::partition(first, last, [&](const Prim &p) {
@@ -105,7 +106,7 @@ struct Builder {
 
     static int scan_threads(int64_t count) {
         if (count < PAR_COUNT) return 1;
-        const int hw = (int)std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+        const int hw = host_threads();
         return (int)std::min<int64_t>(hw, count / (PAR_COUNT / 4));
     }
     template <typename Fn>
@@ -242,11 +243,11 @@ struct Builder {
 };
 
 
-// fn(begin, end) over [0, n) on up to 16 threads
+// fn(begin, end) over [0, n) on up to host_threads() threads
 template <typename Fn>
 void par_for(int64_t n, Fn fn) {
     const int64_t minChunk = 16384;
-    const int threads = (int)std::min<int64_t>(std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u), (n + minChunk - 1) / minChunk);
+    const int threads = (int)std::min<int64_t>(host_threads(), (n + minChunk - 1) / minChunk);
     if (threads <= 1) { fn((int64_t)0, n); return; }
     std::vector<std::thread> pool;
     const int64_t per = (n + threads - 1) / threads;
@@ -327,7 +328,7 @@ void collapse_wide(const Builder &b, uint32_t root, Accel &out) {
         }
     };
     {
-        const int threads = (int)std::min<size_t>(std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u), std::max<size_t>(nSub, 1));
+        const int threads = (int)std::min<size_t>((size_t)host_threads(), std::max<size_t>(nSub, 1));
         std::vector<std::thread> pool;
         for (int t = 1; t < threads; t++) pool.emplace_back(worker);
         worker();
@@ -444,7 +445,7 @@ int build_accel(const RtTriangle *tris, int64_t n, float sceneMaxAbs, int leafMa
     Box rootBox;
     uint32_t root;
     if (getenv("RT_AMD_NO_SIZE_CLASSES")) {
-        root = b.build(0, n, rootBox, 3);
+        root = b.build(0, n, rootBox, host_fork_levels());
     } else {
         Box all = b.bounds(0, n);
         const float ext = std::max(all.mx[0] - all.mn[0], std::max(all.mx[1] - all.mn[1], all.mx[2] - all.mn[2]));

@@ -347,7 +347,7 @@ static int build_tree(RtTriangle *tris, int64_t n, RtLinearBVHNode *nodes, int64
     Build b;
     b.recs = recs.data(); b.nodes = nodes; b.sweep = sweep;
     if (sweep) { b.left.resize((size_t)n); b.right.resize((size_t)n); }
-    b.range(0, n, 0, sweep ? 0 : 3);
+    b.range(0, n, 0, sweep ? 0 : std::min(rt::host_fork_levels(), 3));
     // permute the caller's triangles into tree order and store their centres
     std::vector<RtTriangle> tmp(tris, tris + n);
     for (int64_t i = 0; i < n; i++) {

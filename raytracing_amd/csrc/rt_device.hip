@@ -557,7 +557,13 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                     const int leader = __ffsll((long long)freeMask) - 1;
                     if ((int)lane == leader) base = atomicAdd(workHead, chunk);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // scalar: the chunk bookkeeping stays wave uniform
-                    if (base >= total) { exhausted = true; break; }
+                    if (base >= total) {
+                        exhausted = true;
+#ifdef RT_EXP_TAILPRIO
+                        __builtin_amdgcn_s_setprio(RT_EXP_TAILPRIO);
+#endif
+                        break;
+                    }
                     cNext = base;
                     cEnd = (total - base < chunk) ? total : base + chunk;
                     cSlot = base / framePix;
@@ -735,7 +741,7 @@ static __device__ __align__(256) uint32_t scratch[NOALLOC_SCRATCH_WORDS];
 
 // ====================================================================== host side
 
-constexpr int NSLOT = 3;
+constexpr int NSLOT = 4;
 
 struct RtContext {
     int device = 0;
@@ -800,6 +806,7 @@ struct RtContext {
     bool inputDirty = false;        // work enqueued on `stream` (reset, restore) that the slots' streams must wait for
     hipEvent_t inputEvent = nullptr;
     int nSlots = 0;             // launch slots in use (RtOptions.overlap): 0 = by the size of the batch, else 2..NSLOT
+    int gridDiv = 0;            // experiment (RT_AMD_GRID_DIV): overlapped launches use 1/gridDiv of the resident grid
     int pathsOcc = 0;           // waves per SIMD the path kernel is compiled for (5, 6 or 7); 0 = by scene size
     int pathsLeafBatch = 8;     // lanes waiting for a triangle pass that trigger one in the path kernel
     WorkCounters *dCounters = nullptr;
@@ -893,11 +900,11 @@ int resolve_events(RtContext *ctx) {
     return rc;
 }
 
-// fn(begin, end) over [0, n) on up to 16 host threads (the upload's per-record conversions).
+// fn(begin, end) over [0, n) on up to rt::host_threads() host threads (the upload's per-record conversions).
 template <typename Fn>
 void parallel_for(int64_t n, Fn fn) {
     const int64_t minChunk = 32768;
-    int threads = (int)std::min<int64_t>(std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u), (n + minChunk - 1) / minChunk);
+    int threads = (int)std::min<int64_t>(rt::host_threads(), (n + minChunk - 1) / minChunk);
     if (threads <= 1) { fn((int64_t)0, n); return; }
     std::vector<std::thread> pool;
     const int64_t per = (n + threads - 1) / threads;
@@ -1133,6 +1140,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
     }
     if (const char *env = getenv("RT_AMD_PATHS_OCC")) ctx->pathsOcc = atoi(env);
     if (const char *env = getenv("RT_AMD_SLOTS")) { const int v = atoi(env); if (v >= 2 && v <= NSLOT) ctx->nSlots = v; }
+    if (const char *env = getenv("RT_AMD_GRID_DIV")) { const int v = atoi(env); if (v >= 1 && v <= 8) ctx->gridDiv = v; }
     if (const char *env = getenv("RT_AMD_PATHS_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) ctx->pathsLeafBatch = v; }
     if (const char *env = getenv("RT_AMD_ACCEL_LDS_ENTRIES")) {
         const int v = atoi(env);
@@ -1492,7 +1500,8 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
         const bool fast = ctx->opt.accel != 0 && S.anodes != nullptr;
         // one block per resident slot: 4 waves per block, so waves per SIMD = blocks per CU
         const int occ = ext ? 5 : paths_occupancy(ctx);
-        const int blocks = ctx->numCU * (fast ? occ : 5) * (BLOCK / PATHS_BLOCK);
+        int blocks = ctx->numCU * (fast ? occ : 5) * (BLOCK / PATHS_BLOCK);
+        if (overlap && ctx->gridDiv > 1) blocks = std::max(blocks / ctx->gridDiv, 1);
         const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
         if (overlap) {
             // Everything enqueued on the context's stream before this call - by the caller (a collective
@@ -1510,10 +1519,13 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
                     if (o.stream) HIP_TRY(ctx, hipStreamWaitEvent(o.stream, ctx->inputEvent, 0));
             }
         }
-        for (int off = 0; off < count; off += cap) {
+        // batches of equal size (64 frames where a launch holds 21 are four launches of 16, not 21 + 21 + 21 + 1)
+        const int nBatches = (count + cap - 1) / cap;
+        const int perBatch = (count + nBatches - 1) / nBatches;
+        for (int off = 0; off < count; off += perBatch) {
             BatchD B;
             B.firstLoopNum = first_loopnum + off;
-            B.nframes = std::min(cap, count - off);
+            B.nframes = std::min(perBatch, count - off);
             B.bitsX = bitsX; B.bitsY = bitsY;
             for (int f = 0; f < PATHS_MAX_FRAMES; f++) B.randOrigin[f] = f < B.nframes ? rand_origin[off + f] : 0.0f;
             // Launch slots: a third one pays for small batches, whose launches are mostly tail (one

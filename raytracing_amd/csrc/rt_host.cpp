@@ -1,9 +1,12 @@
 // Host-side pieces of the shader-pass boundary that need no GPU: the Sobol table and its
 // CPU twin, the camera uniforms, the explicit randOrigin generator, error strings.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "rt_internal.h"
 
@@ -12,6 +15,17 @@ namespace rt {
 static std::mutex g_err_mutex;
 static std::string g_err;
 static thread_local std::string g_err_copy;
+
+int host_threads() {
+    if (const char *env = getenv("RT_AMD_HOST_THREADS")) { const int v = atoi(env); if (v >= 1 && v <= 64) return v; }
+    return (int)std::min<unsigned>(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+}
+
+int host_fork_levels() {
+    int levels = 0;
+    for (int t = host_threads(); t > 1; t >>= 1) levels++;
+    return levels;
+}
 
 void set_global_error(const std::string &msg) {
     std::lock_guard<std::mutex> lock(g_err_mutex);

@@ -12,6 +12,13 @@ namespace rt {
 void set_global_error(const std::string &msg);
 const char *global_error();
 
+// Worker threads the host-side builders may use at once: RT_AMD_HOST_THREADS (1..64) when set,
+// else the machine's hardware threads, at most 16.  A job that runs one process per GPU sets the
+// variable so that the ranks together do not oversubscribe the host.
+int host_threads();
+// Levels of two-way forks that stay within host_threads().
+int host_fork_levels();
+
 // Host-side mesh as the reference's loader leaves it (Mesh.h:18-151, data fields only):
 // un-indexed triangles plus the per-mesh Ka/Kd/Ks of Model.h:158-165.
 struct HostMesh {

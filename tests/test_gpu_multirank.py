@@ -7,7 +7,7 @@ import socket
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  (before raytracing_amd: the spawned ranks import this module first, see conftest.py)
+import torch  # noqa: F401
 
 import raytracing_amd as rt
 from raytracing_amd import partition

@@ -23,7 +23,11 @@ WORK = {
     "sponza_gi": ["--kind", "1", "--level", "64", "--width", "3840", "--height", "2160", "--frames", "21", "--warmup", "4", "--gpu-index"],
     "stress10m_gi": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "8", "--gpu-index"],
     "dragon1m_f8": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "32", "--per-call", "8"],
-    "dragon1m_f1": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "32", "--warmup", "8", "--per-call", "1"],
+    "dragon1m_f1": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "8", "--per-call", "1"],
+    "dragon1m_f2": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "8", "--per-call", "2"],
+    "demo_f1": ["--demo", "--frames", "64", "--warmup", "8", "--per-call", "1"],
+    "stress10m_f1": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "8", "--per-call", "1"],
+    "sponza_f1": ["--kind", "1", "--level", "64", "--width", "3840", "--height", "2160", "--frames", "24", "--warmup", "4", "--per-call", "1"],
 }
 
 
