@@ -380,6 +380,16 @@ int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d
  * square root, and the pixel coordinate (X + 0.5) / W of every pixel of every width up to 16384
  * (mismatches[3]): all four counts must be 0. */
 int rt_selftest_nth_element(float *keys, int32_t *ids, int64_t n, int64_t nth);
+/* rt_selftest_index_build: the host build of the library's own search index (RtOptions.accel,
+ * RT_INDEX_BUILD_HOST) for tris[0..n) without a GPU: *node_count 4-wide nodes of 64 bytes in the
+ * layout the kernels read (origin xyz, scale x, four child refs - interior: node index, leaf:
+ * 0x80000000 | triangle number, empty: 0xFFFFFFFF -, 8-bit box bounds qlo xyz / qhi xyz with child c
+ * in bits 8c..8c+7, scale y, scale z) copied to nodes_out when it is not NULL; stats = build
+ * time in ms, levels of wide nodes, summed surface area of the nodes over the root's (wide nodes a
+ * random ray through the root box visits), bound on the deferred-node stack.  scene_max_abs: largest
+ * |coordinate| of the scene. */
+int rt_selftest_index_build(const RtTriangle *tris, int64_t n, float scene_max_abs, void *nodes_out,
+                            int64_t node_capacity, int64_t *node_count, double stats[4]);
 int rt_selftest_sort(float *keys, int32_t *ids, int64_t n);     /* the builder's sort against std::sort */
 int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out);
 int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[4]);

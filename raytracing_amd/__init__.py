@@ -165,6 +165,7 @@ _PROTOS = {
     "rt_get_scene_info": (_int, [_vp, C.POINTER(RtSceneInfo)]),
     "rt_selftest_nth_element": (_int, [_vp, _vp, _i64, _i64]),
     "rt_selftest_arith": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "rt_selftest_index_build": (_int, [_vp, _i64, C.c_float, _vp, _i64, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "rt_selftest_exact_math": (_int, [_vp, C.POINTER(C.c_uint64)]),
     "rt_last_error": (C.c_char_p, [_vp]),
     "rt_version": (C.c_char_p, []),
@@ -254,6 +255,24 @@ def bvh_build(tris, sweep=False):
     cnt = C.c_int64(0)
     _check((lib.rt_bvh_build_sweep if sweep else lib.rt_bvh_build)(_ptr(tris), n, _ptr(nodes), nodes.shape[0], C.byref(cnt)))
     return tris, nodes[:cnt.value]
+
+
+WIDE_NODE_DTYPE = np.dtype([("origin", "<f4", 3), ("scaleX", "<f4"), ("ref", "<u4", 4), ("qlo", "<u4", 3), ("qhi", "<u4", 3),
+                            ("scaleY", "<f4"), ("scaleZ", "<f4")])
+assert WIDE_NODE_DTYPE.itemsize == 64
+
+
+def index_build_host(tris, want_nodes=True):
+    """The host build of the search index alone (no GPU): (4-wide nodes or None, stats dict)."""
+    tris = np.ascontiguousarray(tris, dtype=TRIANGLE_DTYPE)
+    n = tris.shape[0]
+    max_abs = float(np.abs(tris["v"]).max())
+    cnt = C.c_int64(0)
+    stats = (C.c_double * 4)()
+    nodes = np.zeros(max(n, 1), dtype=WIDE_NODE_DTYPE) if want_nodes else None
+    _check(lib.rt_selftest_index_build(_ptr(tris), n, max_abs, _ptr(nodes) if want_nodes else None, max(n, 1), C.byref(cnt), stats))
+    info = {"build_ms": stats[0], "levels": int(stats[1]), "expected_visits": stats[2], "stack_bound": int(stats[3]), "nodes": cnt.value}
+    return (nodes[:cnt.value] if want_nodes else None), info
 
 
 def pack_textures(tris, nodes):
