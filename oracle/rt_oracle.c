@@ -375,7 +375,8 @@ static v3 albedo_texel(const OrScene *sc, const Tri *tri, v3 P) {
         float c = MADD(w2, tri->uv[2][k], MADD(w1, tri->uv[1][k], w0 * tri->uv[0][k])) / sum;
         int size = k ? sc->albedoTexH : sc->albedoTexW;
         if (!(fabsf(c) < INFINITY)) c = 0.0f;
-        float frac = c - floorf(c);
+        float frac = c - floorf(c);             /* GL_REPEAT: the fractional part ... */
+        if (frac >= 1.0f) frac = 0.0f;          /* ... which rounds to 1 for a tiny negative c: that wraps to texel 0 */
         int i = (int)(frac * (float)size);
         xy[k] = i > size - 1 ? size - 1 : i;
     }

@@ -449,6 +449,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
 #ifdef RT_EXP_TIMELINE
     const unsigned long long tlStart = wall_clock64();
     unsigned long long tlIter = 0, tlExhausted = 0;
+    uint32_t tlRetrace = 0;
 #endif
     typename std::conditional<FAST, FastTrav<COUNT>, Trav<CULL, COUNT>>::type tv;
     tv.cur = REF_NONE;
@@ -512,6 +513,15 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 if (fin) {
                     exact = tv.tie || !tv.usable(S);
                     if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
+#ifdef RT_EXP_TIMELINE
+                    // experiment builds: why rays are traced again (the work counters are free when COUNT is off)
+                    if (!COUNT && exact) {
+                        if (tv.tie) atomicAdd(&wc->node_tests, 1ull);
+                        else if (!tv.usable(S)) atomicAdd(&wc->tri_tests, 1ull);
+                        else atomicAdd(&wc->tri_hits, 1ull);
+                        tlRetrace++;
+                    }
+#endif
                 }
                 if (ballot64(exact) != 0ull) {
                     if (exact) {
@@ -648,11 +658,11 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
     }
 #ifdef RT_EXP_TIMELINE
     if (S.timeline) {
-        uint32_t r = cRays;
-        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+        uint32_t r = cRays, rt2 = tlRetrace;
+        for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt2 += __shfl_down(rt2, off); }
         if (lane == 0) {
             unsigned long long *o = S.timeline + (size_t)(blockIdx.x * (PATHS_BLOCK / 64) + (threadIdx.x >> 6)) * 5;
-            o[0] = tlStart; o[1] = wall_clock64(); o[2] = r; o[3] = tlIter; o[4] = tlExhausted;
+            o[0] = tlStart; o[1] = wall_clock64(); o[2] = r | ((unsigned long long)rt2 << 32); o[3] = tlIter; o[4] = tlExhausted;
         }
     }
 #endif
@@ -1050,7 +1060,7 @@ int paths_frames_cap(const RtContext *ctx) {
     const size_t perFrame = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
     const size_t tiles = (size_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
     int g = (int)std::min<size_t>(PATHS_MAX_FRAMES, std::max<size_t>(1, ((size_t)2 << 30) / perFrame));
-    g = std::min(g, (int)std::min<uint32_t>(64u, 1u << (29 - bitsX - bitsY)));      // 3 bits of the pixel word hold the bounce
+    g = std::min(g, (int)std::min<uint32_t>(64u, 1u << (29 - bitsX - bitsY)));      // frame slot, py and px share the lane's 32-bit pixel word (three bits to spare)
     g = (int)std::min<size_t>((size_t)g, std::max<size_t>(1, ((size_t)1 << 31) / (tiles * 64 + 1)));
     if (const char *env = getenv("RT_AMD_BATCH_FRAMES")) { const int v = atoi(env); if (v >= 1 && v < g) g = v; }
     return g;

@@ -141,8 +141,11 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
             float cv = rtm::madd(w2, u1.y, rtm::madd(w1, u0.w, w0 * u0.y)) / sum;
             if (!(fabsf(cu) < INFINITY)) cu = 0.0f;
             if (!(fabsf(cv) < INFINITY)) cv = 0.0f;
-            const int tx = min((int)((cu - floorf(cu)) * (float)S.texW), S.texW - 1);
-            const int ty = min((int)((cv - floorf(cv)) * (float)S.texH), S.texH - 1);
+            float fu = cu - floorf(cu), fv = cv - floorf(cv);
+            if (fu >= 1.0f) fu = 0.0f;          // a tiny negative coordinate has the fractional part 1 in fp32: GL_REPEAT wraps it to texel 0
+            if (fv >= 1.0f) fv = 0.0f;
+            const int tx = min((int)(fu * (float)S.texW), S.texW - 1);
+            const int ty = min((int)(fv * (float)S.texH), S.texH - 1);
             const uint8_t *px = S.texels + ((size_t)ty * (size_t)S.texW + (size_t)tx) * 3;
             texel = rtm::mk((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
         }

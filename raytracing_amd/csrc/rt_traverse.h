@@ -164,8 +164,7 @@ struct Trav {
 
 template <bool CULL, bool COUNT>
 __device__ __forceinline__ void wave_advance(Trav<CULL, COUNT> &tv, const SceneD &S, uint32_t *stack, const int stride,
-                                             uint32_t &nNode, uint32_t &nTri, unsigned long long mInterior,
-                                             unsigned long long mLeaf) {
+                                             uint32_t &nNode, uint32_t &nTri) {
     // every working lane advances by one step per iteration
     if (tv.at_interior()) tv.node_step(S, stack, stride, nNode);
     else if (tv.at_leaf()) tv.leaf_step(S, stack, stride, nTri);
@@ -183,7 +182,7 @@ __device__ __forceinline__ void closest_triangle(const SceneD &S, const vec3 o, 
         const unsigned long long mI = ballot64(tv.at_interior());
         const unsigned long long mL = ballot64(tv.at_leaf());
         if ((mI | mL) == 0ull) break;
-        wave_advance(tv, S, stack, stride, nNode, nTri, mI, mL);
+        wave_advance(tv, S, stack, stride, nNode, nTri);
     }
     tOut = tv.hitMin;
     triOut = tv.best;

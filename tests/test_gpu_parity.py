@@ -707,6 +707,8 @@ def test_albedo_texture_at_interpolated_texture_coordinates(golden_dir, tmp_path
     t = sc.triangles()
     t["tex"] = t["tex"] * np.float32(3.7) - np.float32(1.3)
     t["tex"][:20] = t["v"][:20][:, :, [0, 2]] * np.float32(0.23) + t["v"][:20][:, :, [1, 1]] * np.float32(0.31)   # the room: from positions
+    t["tex"][4:8, :, 0] = np.float32(-1e-9)     # just below a whole number: fractional part 1.0 in fp32, wraps to the first texel
+    t["tex"][4:8, :, 1] = np.float32(-2.75)
     tris, nodes = rt.bvh_build(t)
     image = np.random.default_rng(11).integers(0, 256, (23, 37, 3)).astype(np.uint8)
     cam = rt.CameraRig(W, H).uniforms()

@@ -155,3 +155,11 @@ def test_albedo_texture_mode_of_the_oracle():
     scaled = tris.copy()
     scaled["kd"] = tris["kd"] * (two[0, pick].astype(np.float32) / np.float32(255.0))
     assert eq(render(t, albedo_texture=two), render(scaled))
+    # a coordinate just below a whole number: its fractional part rounds to 1 in fp32, and GL_REPEAT
+    # wraps that to the FIRST texel, not the last
+    t["tex"][:, :, 0] = np.float32(-1e-9)
+    t["tex"][:, :, 1] = np.float32(-2.75)
+    assert np.float32(-1e-9) - np.floor(np.float32(-1e-9)) == np.float32(1.0)
+    four = np.array([[[200, 30, 90], [10, 250, 120]], [[90, 90, 10], [20, 40, 250]]], dtype=np.uint8)
+    scaled["kd"] = tris["kd"] * (four[0, 0].astype(np.float32) / np.float32(255.0))
+    assert eq(render(t, albedo_texture=four), render(scaled))

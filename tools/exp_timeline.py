@@ -21,6 +21,10 @@ waves = 256 * int(os.environ.get("WAVES_PER_SIMD", "7")) * 4
 buf = np.zeros((waves, 5), dtype=np.uint64)
 rt.lib.rt_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 assert rt.lib.rt_debug_timeline(r._h, buf.ctypes.data_as(C.c_void_p), waves) == 0
+retr = (buf[:, 2] >> np.uint64(32)).astype(np.int64)          # rays of the wave traced again in reference order
+buf[:, 2] &= np.uint64(0xFFFFFFFF)
+st = r.stats()
+print(f"rays traced again: {st['retraced']} (ties {st['node_tests']}, unusable rays {st['tri_tests']}, reference does not reach the triangle {st['tri_hits']})")
 t0 = buf[:, 0].astype(np.float64); t1 = buf[:, 1].astype(np.float64); ex = buf[:, 4].astype(np.float64)
 base = t0.min()
 tick = 1e-2     # wall_clock64 ticks at 100 MHz -> microseconds
@@ -39,3 +43,7 @@ for h, e in zip(hist, edges):
     print(f"  ends at {e:7.0f} us: {h}")
 tail = ((t1 - ex) * tick)[ex > 0]
 print(f"after work ran out a wave lives: median {np.median(tail):.0f}, p90 {np.percentile(tail, 90):.0f}, max {tail.max():.0f} us")
+endt = (t1 - base) * tick
+order = np.argsort(endt)[::-1][:12]
+print("last waves to end (us, rays traced again in the wave):", [(int(endt[i]), int(retr[i])) for i in order])
+print(f"waves with a re-trace: {int((retr > 0).sum())}; their end: median {np.median(endt[retr > 0]) if (retr > 0).any() else 0:.0f} us; others: p99 {np.percentile(endt[retr == 0], 99):.0f}, max {endt[retr == 0].max():.0f} us")
