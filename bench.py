@@ -91,19 +91,22 @@ def frames_per_launch(frames_per_call, cap):
 
 
 def call_granularity(r, ro, opts, frames=64):
-    """The drop-in call pattern: the reference's main loop (main.cpp:124-172) renders ONE frame per
-    iteration, i.e. rt_render_frames(ctx, LoopNum, 1, &randOrigin).  Times `frames` frames issued
-    as calls of 1 and of 8 frames (no host synchronisation between calls) next to the batched
-    figure of the main measurement."""
+    """The drop-in call pattern: the reference's main loop (main.cpp:124-197) renders ONE frame per
+    iteration, rt_render_frames(ctx, LoopNum, 1, &randOrigin), and displays the image after every
+    frame.  Times `frames` frames issued as calls of 1 and of 8 frames: pipelined (no host
+    synchronisation between calls) with RtOptions.coalesce on (the default: calls issued while the
+    GPU is busy are launched together) and off (one launch per call), and one frame per call
+    followed by rt_synchronize or by rt_read_mean (a blocking copy of the W*H*3 floats to the
+    host).  Runs on the library's own sum buffer: with a caller-owned buffer bound, as in the
+    main measurement, calls are never coalesced."""
     out = []
     frames = min(frames, len(ro) // 8 * 8)
     if frames < 8:
         return out
-    r.set_options(count_work=False, **opts)
-    # (frames per call, what follows every call): nothing = calls pipelined on the GPU; "read_mean" = the
-    # reference's loop, which displays the image after every frame (main.cpp:178-197: a blocking
-    # device-to-host copy of W*H*3 floats here); "synchronize" = the same wait without the copy
-    for per_call, after in ((1, None), (8, None), (1, "synchronize"), (1, "read_mean")):
+    r.bind_sum_buffer(0)
+    for per_call, after, coalesce in ((1, None, True), (1, None, False), (8, None, True), (8, None, False),
+                                      (1, "synchronize", True), (1, "read_mean", True)):
+        r.set_options(count_work=False, coalesce=coalesce, **opts)
         for timed in (False, True):                         # one untimed pass first
             r.reset()
             r.synchronize()
@@ -117,9 +120,11 @@ def call_granularity(r, ro, opts, frames=64):
             r.synchronize()
             dt = time.perf_counter() - t0
         rays = r.stats()["rays"]
-        out.append({"frames_per_call": per_call, "after_each_call": after or "nothing (pipelined)", "calls": frames // per_call,
-                    "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+        _, launches = r.kernel_time()
+        out.append({"frames_per_call": per_call, "after_each_call": after or "nothing (pipelined)", "coalesce": coalesce,
+                    "calls": frames // per_call, "launches": launches, "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
                     "ms_per_call": round(dt / (frames // per_call) * 1e3, 4)})
+    r.set_options(count_work=False, **opts)
     return out
 
 

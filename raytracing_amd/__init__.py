@@ -103,7 +103,8 @@ class RtSceneInfo(C.Structure):
 class RtOptions(C.Structure):
     _fields_ = [("max_bounces", C.c_int32), ("pipeline", C.c_int32), ("cull", C.c_int32),
                 ("count_work", C.c_int32), ("accel", C.c_int32), ("history8", C.c_int32), ("overlap", C.c_int32),
-                ("index_build", C.c_int32), ("shading_normals", C.c_int32), ("albedo_texture", C.c_int32)]
+                ("index_build", C.c_int32), ("shading_normals", C.c_int32), ("albedo_texture", C.c_int32),
+                ("coalesce", C.c_int32)]
 
 
 _vp, _i64, _int = C.c_void_p, C.c_int64, C.c_int
@@ -367,9 +368,9 @@ class Renderer:
         _check(lib.rt_set_stream(self._h, C.c_void_p(stream_handle)), self._h)
 
     def set_options(self, max_bounces=4, pipeline=PIPELINE_PERSISTENT, cull=True, count_work=False, accel=True,
-                    history8=False, overlap=True, index_build=2, shading_normals=False, albedo_texture=False):
+                    history8=False, overlap=True, index_build=2, shading_normals=False, albedo_texture=False, coalesce=True):
         o = RtOptions(max_bounces, pipeline, int(cull), int(count_work), int(accel), int(history8), int(overlap), int(index_build),
-                      int(shading_normals), int(albedo_texture))
+                      int(shading_normals), int(albedo_texture), int(coalesce))
         _check(lib.rt_set_options(self._h, C.byref(o)), self._h)
 
     def upload(self, tris, nodes):

@@ -813,6 +813,10 @@ struct RtContext {
     size_t ovfBytes = 0;
     int nextSlot = 0;
     int lastSlot = -1;              // slot whose accumulate kernel was enqueued last
+    // RtOptions.coalesce: frames of small rt_render_frames calls that wait for a launch of their own
+    std::vector<float> heldFrames;  // their randOrigin values; LoopNum heldFirst, heldFirst + 1, ...
+    int heldFirst = 0;
+    bool sumPtrGivenOut = false;    // rt_sum_device_ptr was called: the caller may order device work after render calls
     bool inputDirty = false;        // work enqueued on `stream` (reset, restore) that the slots' streams must wait for
     hipEvent_t inputEvent = nullptr;
     int nSlots = 0;             // launch slots in use (RtOptions.overlap): 0 = by the size of the batch, else 2..NSLOT
@@ -862,6 +866,8 @@ std::string loaded_hip_runtimes() {
     for (const auto &f : found) out += (out.empty() ? "" : ", ") + f;
     return out;
 }
+
+int flush_pending(RtContext *ctx);      // launches the frames RtOptions.coalesce holds back (defined with rt_render_frames)
 
 int fail(RtContext *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -1092,6 +1098,7 @@ int rt_default_options(RtOptions *out) {
     out->index_build = RT_INDEX_BUILD_AUTO;
     out->shading_normals = 0;
     out->albedo_texture = 0;
+    out->coalesce = 1;
     return RT_OK;
 }
 
@@ -1196,6 +1203,7 @@ void rt_destroy(RtContext *ctx) {
 
 int rt_set_stream(RtContext *ctx, void *hip_stream) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_set_stream: null context");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, sync_all_streams(ctx));
     ctx->stream = (hipStream_t)hip_stream;
@@ -1205,6 +1213,7 @@ int rt_set_stream(RtContext *ctx, void *hip_stream) {
 
 int rt_set_options(RtContext *ctx, const RtOptions *opt) {
     if (!ctx || !opt) return fail(ctx, RT_E_INVALID, "rt_set_options: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     if (opt->max_bounces < 1 || opt->max_bounces > RT_MAX_BOUNCES) return fail(ctx, RT_E_INVALID, "rt_set_options: max_bounces must be in 1..8");
     if (opt->pipeline != RT_PIPELINE_WAVEFRONT && opt->pipeline != RT_PIPELINE_MEGAKERNEL && opt->pipeline != RT_PIPELINE_PERSISTENT) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown pipeline");
     if (opt->index_build != RT_INDEX_BUILD_HOST && opt->index_build != RT_INDEX_BUILD_GPU && opt->index_build != RT_INDEX_BUILD_AUTO) return fail(ctx, RT_E_INVALID, "rt_set_options: unknown index_build");
@@ -1219,6 +1228,7 @@ int rt_set_options(RtContext *ctx, const RtOptions *opt) {
 
 int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtLinearBVHNode *nodes, int64_t m) {
     if (!ctx || !tris || !nodes) return fail(ctx, RT_E_INVALID, "rt_scene_upload: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     std::vector<float4> hNodes, hTris, hMats; SceneD S;
     bool boxesExact = true;
     const double tStart = now_ms();
@@ -1384,6 +1394,7 @@ int rt_scene_upload_textures(RtContext *ctx, const float *tex_triangle, int64_t 
 
 int rt_set_albedo_texture(RtContext *ctx, const uint8_t *rgb, int width, int height) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_set_albedo_texture: null context");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     if (rgb && (width < 1 || height < 1 || width > 16384 || height > 16384))
         return fail(ctx, RT_E_INVALID, "rt_set_albedo_texture: width/height must be in 1..16384");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1400,6 +1411,7 @@ int rt_set_albedo_texture(RtContext *ctx, const uint8_t *rgb, int width, int hei
 
 int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]) {
     if (!ctx || !v) return fail(ctx, RT_E_INVALID, "rt_set_sobol: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     std::memcpy(ctx->sobol, v, sizeof ctx->sobol);
     // stream ordered: frames already queued keep the old table
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1410,6 +1422,7 @@ int rt_set_sobol(RtContext *ctx, const uint32_t v[RT_SOBOL_WORDS]) {
 
 int rt_set_spheres(RtContext *ctx, const RtSphere *spheres, int count) {
     if (!ctx || count < 0 || count > RT_MAX_SPHERES || (count > 0 && !spheres)) return fail(ctx, RT_E_INVALID, "rt_set_spheres: count must be in 0..10");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     ctx->frame.sphereNum = count;
     for (int i = 0; i < count; i++) ctx->frame.sph[i] = spheres[i];
     return RT_OK;
@@ -1417,6 +1430,7 @@ int rt_set_spheres(RtContext *ctx, const RtSphere *spheres, int count) {
 
 int rt_set_camera(RtContext *ctx, const RtCamera *cam) {
     if (!ctx || !cam) return fail(ctx, RT_E_INVALID, "rt_set_camera: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     ctx->frame.cam = *cam;
     ctx->haveCamera = true;
     return RT_OK;
@@ -1424,6 +1438,7 @@ int rt_set_camera(RtContext *ctx, const RtCamera *cam) {
 
 int rt_reset(RtContext *ctx) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_reset: null context");
+    ctx->heldFrames.clear();        // frames not launched yet would be cleared with the rest
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t img = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
     HIP_TRY(ctx, hipMemsetAsync(ctx->dSum, 0, img, ctx->stream));
@@ -1439,10 +1454,39 @@ int rt_reset(RtContext *ctx) {
 
 int rt_synchronize(RtContext *ctx) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_synchronize: null context");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+int render_now(RtContext *ctx, int first_loopnum, int count, const float *rand_origin);
+
+// Launches the frames that earlier calls of rt_render_frames left waiting (RtOptions.coalesce).
+// Every entry point that reads or changes what a frame depends on calls this first.
+int flush_pending(RtContext *ctx) {
+    if (ctx->heldFrames.empty()) return RT_OK;
+    std::vector<float> ro;
+    ro.swap(ctx->heldFrames);           // render_now may fail: the frames are gone either way, as after any failed call
+    return render_now(ctx, ctx->heldFirst, (int)ro.size(), ro.data());
+}
+
+// Batches of this context that the GPU has not finished yet.
+int batches_in_flight(RtContext *ctx) {
+    int n = 0;
+    for (auto &sl : ctx->slot)
+        if (sl.used && sl.accDone && hipEventQuery(sl.accDone) == hipErrorNotReady) n++;
+    (void)hipGetLastError();
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
 
 int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *rand_origin) {
     if (!ctx || !rand_origin) return fail(ctx, RT_E_INVALID, "rt_render_frames: null pointer");
@@ -1450,6 +1494,35 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_render_frames: no scene uploaded");
     if (!ctx->haveCamera) return fail(ctx, RT_E_STATE, "rt_render_frames: no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // RtOptions.coalesce: while two batches are still running, the frames of small calls wait on the
+    // host and go out together.  A launch of one 1080p frame spends a fifth of its paths in waves
+    // that only drain (nothing refills their lanes), a launch of eight frames a fortieth; the GPU
+    // is busy either way, so the wait costs nothing.  Only where the caller cannot tell the
+    // difference: not with a stream of its own, a bound sum buffer or the sum buffer's address in
+    // its hands, all of which let it order device work after "the frames of the calls so far".
+    const int cap = paths_frames_cap(ctx);
+    const bool mayHold = ctx->opt.coalesce != 0 && ctx->opt.pipeline == RT_PIPELINE_PERSISTENT && ctx->opt.overlap != 0 &&
+                         ctx->stream == nullptr && ctx->dSum == ctx->dSumOwned && !ctx->sumPtrGivenOut && count < cap;
+    if (!mayHold) {
+        const int rc = flush_pending(ctx);
+        if (rc != RT_OK) return rc;
+        return render_now(ctx, first_loopnum, count, rand_origin);
+    }
+    if (!ctx->heldFrames.empty() && (first_loopnum != ctx->heldFirst + (int)ctx->heldFrames.size() || (int)ctx->heldFrames.size() + count > cap)) {
+        const int rc = flush_pending(ctx);
+        if (rc != RT_OK) return rc;
+    }
+    if (ctx->heldFrames.empty()) ctx->heldFirst = first_loopnum;
+    ctx->heldFrames.insert(ctx->heldFrames.end(), rand_origin, rand_origin + count);
+    if ((int)ctx->heldFrames.size() >= cap || batches_in_flight(ctx) < 2) return flush_pending(ctx);
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int render_now(RtContext *ctx, int first_loopnum, int count, const float *rand_origin) {
     int rc = RT_OK;
     if (ctx->pendingEvents.size() > 8192) { rc = resolve_events(ctx); if (rc != RT_OK) return rc; }
     const FrameD &F = ctx->frame;
@@ -1600,6 +1673,7 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
             HIP_TRY(ctx, hipGetLastError());
             if (overlap) {
                 HIP_TRY(ctx, hipEventRecord(sl.accDone, ps));
+                sl.used = true;
                 ctx->lastSlot = si;
                 // whatever follows on the context's stream (reads, resets, the caller's own work) sees this batch
                 HIP_TRY(ctx, hipStreamWaitEvent(st, sl.accDone, 0));
@@ -1655,8 +1729,13 @@ int rt_render_frames(RtContext *ctx, int first_loopnum, int count, const float *
     return RT_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int rt_read_mean(RtContext *ctx, float *rgb) {
     if (!ctx || !rgb) return fail(ctx, RT_E_INVALID, "rt_read_mean: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dMean, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1665,6 +1744,7 @@ int rt_read_mean(RtContext *ctx, float *rgb) {
 
 int rt_read_sum(RtContext *ctx, float *rgb) {
     if (!ctx || !rgb) return fail(ctx, RT_E_INVALID, "rt_read_sum: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dSum, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1673,6 +1753,7 @@ int rt_read_sum(RtContext *ctx, float *rgb) {
 
 int rt_restore(RtContext *ctx, const float *mean_rgb, const float *sum_rgb, uint64_t frames) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_restore: null context");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     if (frames >= ((uint64_t)1 << 30)) return fail(ctx, RT_E_INVALID, "rt_restore: frame count out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t img = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
@@ -1686,12 +1767,15 @@ int rt_restore(RtContext *ctx, const float *mean_rgb, const float *sum_rgb, uint
 
 int rt_sum_device_ptr(RtContext *ctx, void **dev_ptr) {
     if (!ctx || !dev_ptr) return fail(ctx, RT_E_INVALID, "rt_sum_device_ptr: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
+    ctx->sumPtrGivenOut = true;     // from now on every call launches its frames before it returns
     *dev_ptr = ctx->dSum;
     return RT_OK;
 }
 
 int rt_bind_sum_buffer(RtContext *ctx, float *dev_ptr) {
     if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_bind_sum_buffer: null context");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->dSum = dev_ptr ? dev_ptr : ctx->dSumOwned;
@@ -1700,6 +1784,7 @@ int rt_bind_sum_buffer(RtContext *ctx, float *dev_ptr) {
 
 int rt_get_stats(RtContext *ctx, RtStats *out) {
     if (!ctx || !out) return fail(ctx, RT_E_INVALID, "rt_get_stats: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     WorkCounters wc;
     HIP_TRY(ctx, hipMemcpyAsync(&wc, ctx->dCounters, sizeof wc, hipMemcpyDeviceToHost, ctx->stream));
@@ -1748,6 +1833,7 @@ int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[4]) {
 
 int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches) {
     if (!ctx || !total_ms || !launches) return fail(ctx, RT_E_INVALID, "rt_get_kernel_time: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     int rc = resolve_events(ctx);
@@ -1758,6 +1844,7 @@ int rt_get_kernel_time(RtContext *ctx, double *total_ms, int64_t *launches) {
 int rt_trace_rays(RtContext *ctx, const float *origins, const float *dirs, int64_t n, float *t_out, int32_t *id_out) {
     if (!ctx || !origins || !dirs || !t_out || !id_out || n < 0) return fail(ctx, RT_E_INVALID, "rt_trace_rays: bad argument");
     if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_trace_rays: no scene uploaded");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     if (n == 0) return RT_OK;
     if (n > (int64_t)1 << 26) return fail(ctx, RT_E_INVALID, "rt_trace_rays: more than 2^26 rays per call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1817,6 +1904,7 @@ int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d
     if (!ctx || !d_origins || !d_dirs || !d_t_out || !d_id_out || n < 0) return fail(ctx, RT_E_INVALID, "rt_trace_rays_noalloc: bad argument");
     if (n > (int64_t)RT_NOALLOC_MAX_RAYS) return fail(ctx, RT_E_INVALID, "rt_trace_rays_noalloc: more than RT_NOALLOC_MAX_RAYS (262144) rays per call");
     if (!ctx->haveScene) return fail(ctx, RT_E_STATE, "rt_trace_rays_noalloc: no scene uploaded");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t *base = (ctx->device >= 0 && ctx->device < MAX_DEVICES) ? g_scratchPtr[ctx->device] : nullptr;

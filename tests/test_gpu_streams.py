@@ -136,3 +136,76 @@ def test_explicit_gpu_index_build_falls_back_to_the_host(monkeypatch):
     info = r.scene_info()
     assert info["index_built_on_device"] == 1 and info["index_build_fell_back"] == 0
     r.close()
+
+
+def test_coalesced_calls_give_the_same_images_and_launch_less_often():
+    """RtOptions.coalesce: small calls issued while the GPU is busy are collected and launched
+    together.  Whatever the caller does in between - reads, camera changes, resets, statistics -
+    the result equals that of launching every call at once; a caller that holds the sum buffer
+    (bound, or its address handed out) or a stream of its own gets one launch per call."""
+    import torch
+    Wc, Hc = 480, 270
+    sc = _hall()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam_a = rt.camera_default(Wc, Hc)
+    cam_b = rt.camera_from_angles((1.0, 3.0, 9.0), -100.0, -5.0, 40.0, Wc, Hc)
+    ro = rt.rand_origins(123, 96)
+
+    def scenario(r):
+        out = []
+        for k in range(40):                                 # forty calls of one frame, no waiting
+            r.render(k + 1, ro[k:k + 1])
+        out.append(r.read_mean())
+        for k in range(40, 52, 3):                          # calls of three, then statistics
+            r.render(k + 1, ro[k:k + 3])
+        st = r.stats()
+        out.append((st["frames"], st["rays"]))
+        r.render(53, ro[52:53])
+        r.set_camera(cam_b)                                 # frame 53 belongs to the old camera
+        r.render(54, ro[53:54])
+        r.render(56, ro[55:56])                             # not consecutive: another batch
+        out.append(r.read_sum())
+        r.reset()
+        r.render(1, ro[:2])
+        r.reset()                                           # frames not launched yet go with the reset
+        r.render(1, ro[60:64])
+        r.render(5, ro[64:65])
+        out.append(r.read_mean())
+        out.append(r.stats()["frames"])
+        r.set_camera(cam_a)
+        return out
+
+    res = {}
+    launches = {}
+    for mode in ("each", "coalesce", "bound", "own_stream", "ptr_given"):
+        r = rt.Renderer(Wc, Hc)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam_a)
+        r.set_options(coalesce=(mode != "each"))
+        keep = None
+        if mode == "bound":
+            keep = torch.zeros(Hc * Wc * 3, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            r.bind_sum_buffer(keep.data_ptr())
+        elif mode == "own_stream":
+            keep = torch.cuda.Stream()
+            r.set_stream(keep.cuda_stream)
+        elif mode == "ptr_given":
+            assert r.sum_device_ptr() != 0
+        res[mode] = scenario(r)
+        r.reset()
+        for k in range(48):
+            r.render(k + 1, ro[k:k + 1])
+        launches[mode] = r.kernel_time()[1]
+        if mode == "bound":
+            r.bind_sum_buffer(0)
+        if mode == "own_stream":
+            r.set_stream(0)
+        r.close()
+    for mode in ("coalesce", "bound", "own_stream", "ptr_given"):
+        for a, b in zip(res["each"], res[mode]):
+            assert _eq(a, b) if isinstance(a, np.ndarray) else a == b, mode
+    assert res["each"][1][0] == 52 and res["each"][4] == 5
+    assert launches["each"] == launches["bound"] == launches["own_stream"] == launches["ptr_given"] == 48
+    assert launches["coalesce"] < 48
