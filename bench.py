@@ -96,16 +96,18 @@ def call_granularity(r, ro, opts, frames=64):
     frame.  Times `frames` frames issued as calls of 1 and of 8 frames: pipelined (no host
     synchronisation between calls) with RtOptions.coalesce on (the default: calls issued while the
     GPU is busy are launched together) and off (one launch per call), and one frame per call
-    followed by rt_synchronize or by rt_read_mean (a blocking copy of the W*H*3 floats to the
-    host).  Runs on the library's own sum buffer: with a caller-owned buffer bound, as in the
+    followed by rt_synchronize, by rt_read_mean (a blocking copy of the W*H*3 floats to pageable
+    host memory) or by rt_read_wait + rt_read_mean_async into page-locked memory (frame N is copied
+    and shown while frame N+1 is traced).  Runs on the library's own sum buffer: with a caller-owned buffer bound, as in the
     main measurement, calls are never coalesced."""
     out = []
     frames = min(frames, len(ro) // 8 * 8)
     if frames < 8:
         return out
     r.bind_sum_buffer(0)
+    pinned = [r.host_image(), r.host_image()]
     for per_call, after, coalesce in ((1, None, True), (1, None, False), (8, None, True), (8, None, False),
-                                      (1, "synchronize", True), (1, "read_mean", True)):
+                                      (1, "synchronize", True), (1, "read_mean", True), (1, "read_mean_async", True)):
         r.set_options(count_work=False, coalesce=coalesce, **opts)
         for timed in (False, True):                         # one untimed pass first
             r.reset()
@@ -117,6 +119,10 @@ def call_granularity(r, ro, opts, frames=64):
                     r.read_mean()
                 elif after == "synchronize":
                     r.synchronize()
+                elif after == "read_mean_async":
+                    # show frame N-1 (its copy has had the tracing of frame N to arrive), ask for frame N
+                    r.read_wait()
+                    r.read_mean_async(pinned[(first - 1) % 2])
             r.synchronize()
             dt = time.perf_counter() - t0
         rays = r.stats()["rays"]

@@ -20,6 +20,7 @@
 #ifndef RT_AMD_H
 #define RT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -345,6 +346,23 @@ int rt_synchronize(RtContext *ctx);
  * reference's 8-bit texture): mean_N = sample/N + mean_{N-1}*(N-1)/N, valid when frames were
  * rendered in order from LoopNum 1. */
 int rt_read_mean(RtContext *ctx, float *rgb);
+/* The same image without stopping the pipeline, for a caller that displays after every frame as the
+ * reference's loop does (main.cpp:178-197) and can live with showing frame N while frame N+1 is being
+ * traced: rt_read_mean_async enqueues the copy of the running mean as it stands after the frames of
+ * all calls so far and returns; rt_read_wait blocks until that copy has arrived (rt_synchronize
+ * would also wait for frames requested since).  The path tracing of later calls runs beside the
+ * copy; their frames are added to the image only after it.  rgb should be page-locked host memory
+ * (rt_host_alloc), or the copy is staged and slow.  No counterpart in the reference, whose image
+ * never leaves the GPU. */
+int rt_read_mean_async(RtContext *ctx, float *rgb);
+int rt_read_wait(RtContext *ctx);
+/* Page-locked host memory for image reads (hipHostMalloc); NULL when it cannot be had. */
+void *rt_host_alloc(size_t bytes);
+void rt_host_free(void *p);
+/* Device address of the W*H*3 fp32 running mean, for a consumer on the same GPU (what the
+ * reference's display pass does with its FBO texture, main.cpp:187-190).  Valid after the work on
+ * the context's stream that precedes the read. */
+int rt_mean_device_ptr(RtContext *ctx, void **dev_ptr);
 /* Plain fp32 sum of all samples since rt_reset (what a multi-GPU reduce adds up). */
 int rt_read_sum(RtContext *ctx, float *rgb);
 /* Resume an interrupted render: loads a running mean and a sum read earlier with rt_read_mean /

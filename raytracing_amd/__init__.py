@@ -156,6 +156,11 @@ _PROTOS = {
     "rt_synchronize": (_int, [_vp]),
     "rt_read_mean": (_int, [_vp, _vp]),
     "rt_read_sum": (_int, [_vp, _vp]),
+    "rt_read_mean_async": (_int, [_vp, _vp]),
+    "rt_read_wait": (_int, [_vp]),
+    "rt_mean_device_ptr": (_int, [_vp, C.POINTER(_vp)]),
+    "rt_host_alloc": (_vp, [C.c_size_t]),
+    "rt_host_free": (None, [_vp]),
     "rt_restore": (_int, [_vp, _vp, _vp, C.c_uint64]),
     "rt_sum_device_ptr": (_int, [_vp, C.POINTER(_vp)]),
     "rt_bind_sum_buffer": (_int, [_vp, _vp]),
@@ -355,11 +360,15 @@ class Renderer:
         self._h = h
         self.width, self.height = width, height
         self._keep = []
+        self._pinned = []
 
     def close(self):
         if getattr(self, "_h", None):
-            lib.rt_destroy(self._h)
+            lib.rt_destroy(self._h)         # waits for everything in flight, copies into host_image() arrays included
             self._h = None
+            for p in self._pinned:
+                lib.rt_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         self.close()
@@ -421,6 +430,28 @@ class Renderer:
         out = np.zeros((self.height, self.width, 3), dtype=np.float32)
         _check(lib.rt_read_mean(self._h, _ptr(out)), self._h)
         return out
+
+    def host_image(self):
+        """A (height, width, 3) float32 array in page-locked host memory for read_mean_async; freed with the renderer."""
+        nbytes = self.height * self.width * 3 * 4
+        p = lib.rt_host_alloc(nbytes)
+        if not p:
+            raise RtError("rt_host_alloc failed")
+        self._pinned.append(p)
+        return np.ctypeslib.as_array((C.c_float * (nbytes // 4)).from_address(p)).reshape(self.height, self.width, 3)
+
+    def read_mean_async(self, out):
+        """Enqueues the copy of the running mean into `out` (from host_image()); read_wait() blocks until it is there."""
+        assert out.dtype == np.float32 and out.shape == (self.height, self.width, 3) and out.flags["C_CONTIGUOUS"]
+        _check(lib.rt_read_mean_async(self._h, _ptr(out)), self._h)
+
+    def read_wait(self):
+        _check(lib.rt_read_wait(self._h), self._h)
+
+    def mean_device_ptr(self):
+        p = C.c_void_p()
+        _check(lib.rt_mean_device_ptr(self._h, C.byref(p)), self._h)
+        return p.value
 
     def read_sum(self):
         out = np.zeros((self.height, self.width, 3), dtype=np.float32)

@@ -816,6 +816,8 @@ struct RtContext {
     // RtOptions.coalesce: frames of small rt_render_frames calls that wait for a launch of their own
     std::vector<float> heldFrames;  // their randOrigin values; LoopNum heldFirst, heldFirst + 1, ...
     int heldFirst = 0;
+    hipEvent_t readEvent = nullptr; // end of the last rt_read_mean_async copy
+    bool readPending = false;
     bool sumPtrGivenOut = false;    // rt_sum_device_ptr was called: the caller may order device work after render calls
     bool inputDirty = false;        // work enqueued on `stream` (reset, restore) that the slots' streams must wait for
     hipEvent_t inputEvent = nullptr;
@@ -1198,6 +1200,7 @@ void rt_destroy(RtContext *ctx) {
         hipFree(sl.dCurBatch); hipFree(sl.dWorkHead); hipFree(sl.dSobTable);
     }
     if (ctx->inputEvent) hipEventDestroy(ctx->inputEvent);
+    if (ctx->readEvent) hipEventDestroy(ctx->readEvent);
     delete ctx;
 }
 
@@ -1740,6 +1743,47 @@ int rt_read_mean(RtContext *ctx, float *rgb) {
     HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dMean, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
+}
+
+int rt_read_mean_async(RtContext *ctx, float *rgb) {
+    if (!ctx || !rgb) return fail(ctx, RT_E_INVALID, "rt_read_mean_async: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->readEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->readEvent, hipEventDisableTiming));
+    // On the context's stream: after the accumulation of every frame rendered so far, and before that of
+    // the next call (whose accumulate kernels wait for what is on this stream when the call begins), while
+    // the next call's path tracing, which does not touch the image, runs beside the copy.
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dMean, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->readEvent, ctx->stream));
+    ctx->readPending = true;
+    return RT_OK;
+}
+
+int rt_read_wait(RtContext *ctx) {
+    if (!ctx) return fail(nullptr, RT_E_INVALID, "rt_read_wait: null context");
+    if (!ctx->readPending) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->readEvent));
+    ctx->readPending = false;
+    return RT_OK;
+}
+
+int rt_mean_device_ptr(RtContext *ctx, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return fail(ctx, RT_E_INVALID, "rt_mean_device_ptr: null pointer");
+    { const int frc = flush_pending(ctx); if (frc != RT_OK) return frc; }
+    ctx->sumPtrGivenOut = true;     // the caller can now order device work after render calls: every call launches its frames at once
+    *dev_ptr = ctx->dMean;
+    return RT_OK;
+}
+
+void *rt_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void rt_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int rt_read_sum(RtContext *ctx, float *rgb) {

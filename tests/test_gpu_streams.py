@@ -209,3 +209,35 @@ def test_coalesced_calls_give_the_same_images_and_launch_less_often():
     assert res["each"][1][0] == 52 and res["each"][4] == 5
     assert launches["each"] == launches["bound"] == launches["own_stream"] == launches["ptr_given"] == 48
     assert launches["coalesce"] < 48
+
+
+def test_async_read_shows_frame_n_while_frame_n_plus_one_is_traced():
+    """rt_read_mean_async + rt_read_wait: the display loop of the reference (one frame, then show it)
+    with the copy of frame N overlapping the tracing of frame N+1.  Every image read this way must be
+    the running mean after exactly the frames requested before the read."""
+    Wc, Hc, N = 640, 360, 24
+    sc = _hall()
+    r = rt.make_renderer(sc, Wc, Hc)
+    ro = rt.rand_origins(321, N)
+    want = []
+    for k in range(N):                                      # one frame, wait, read: the plain loop
+        r.render(k + 1, ro[k:k + 1])
+        want.append(r.read_mean())
+    for coalesce in (True, False):
+        r.set_options(coalesce=coalesce)
+        r.reset()
+        bufs = [r.host_image(), r.host_image()]
+        got = []
+        for k in range(N):
+            r.render(k + 1, ro[k:k + 1])
+            if k > 0:
+                r.read_wait()                               # the image of frame k (requested in the last round) has arrived
+                got.append(bufs[(k - 1) % 2].copy())
+            r.read_mean_async(bufs[k % 2])
+        r.read_wait()
+        got.append(bufs[(N - 1) % 2].copy())
+        for k in range(N):
+            assert _eq(got[k], want[k]), (coalesce, k)
+        assert r.stats()["frames"] == N
+    assert r.mean_device_ptr() != 0
+    r.close()
