@@ -5,10 +5,10 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$ROOT"
 declare -A ARGS FR
 ARGS[dragon1m]="--kind 0 --level 8 --copies 1 --frames 64 --warmup 64"; FR[dragon1m]=64
-ARGS[sponza]="--kind 1 --level 64 --width 3840 --height 2160 --frames 21 --warmup 21"; FR[sponza]=21
+ARGS[sponza]="--kind 1 --level 64 --width 3840 --height 2160 --frames 16 --warmup 16"; FR[sponza]=16
 ARGS[stress10m]="--kind 0 --level 8 --copies 8 --bounces 8 --frames 64 --warmup 64"; FR[stress10m]=64
 ARGS[demo]="--demo --frames 64 --warmup 64"; FR[demo]=64
-for w in "${@:-dragon1m sponza stress10m}"; do
+for w in "${@:-dragon1m sponza stress10m demo}"; do
   for ww in $w; do
     out=$ROOT/gpurun_out/prof/$ww
     rm -rf "$out"; mkdir -p "$out"
