@@ -4,7 +4,12 @@
 //             [--sphere CX CY CZ R AR AG AB DIFFUSE_RATE MIRROR_RATE] [--size W H] [--spp N]
 //             [--bounces B] [--seed S] [--camera PX PY PZ YAW PITCH FOV] [--exact] [--megakernel | --wavefront] [--history8]
 //             [--shading-normals] [--texture image.ppm] [--gpu-index | --host-index]
-//             [--out image.pfm] [--ppm image.ppm]
+//             [--frames-per-call N] [--show] [--out image.pfm] [--ppm image.ppm]
+//
+// --frames-per-call 1 is the reference's own loop (one draw per iteration, main.cpp:171); the
+// default hands 64 frames to a call.  --show fetches the image after every call the way a window
+// would show it (main.cpp:178-197), with rt_read_mean_async into page-locked memory: the image of
+// one call arrives while the next call is traced.
 //
 // Loads the scene (Model + Scene::pushModel), builds the BVH in the reference's node order
 // (BVHTree::build / buildLinerTree), uploads it (getTexture), then renders N frames with
@@ -31,6 +36,8 @@ int main(int argc, char **argv) {
     int W = 1200, H = 800, spp = 16, bounces = 4;     // SCR_WIDTH/SCR_HEIGHT of main.cpp:29-30
     uint32_t seed = 20221003u;
     bool exact = false, mega = false, wavefront = false, history8 = false, shadingNormals = false, gpuIndex = false, hostIndex = false, customCam = false, haveGeometry = false;
+    int framesPerCall = 64;       // the path kernel renders up to 64 frames per launch
+    bool show = false;
     float camArgs[6] = {0, 2, 5, -90, 0, 45};
     std::string outPfm, outPpm, texturePpm;
     RtScene *scene = nullptr;
@@ -71,12 +78,15 @@ int main(int argc, char **argv) {
         else if (a == "--texture") { need(1); texturePpm = argv[++i]; }  // diffuse albedo map at the models' vt coordinates (not in the reference)
         else if (a == "--gpu-index") gpuIndex = true;                 // search index built on the device
         else if (a == "--host-index") hostIndex = true;               // ... on the host (default: by scene size)
+        else if (a == "--frames-per-call") { need(1); framesPerCall = atoi(argv[++i]); }
+        else if (a == "--show") show = true;
         else if (a == "--out") { need(1); outPfm = argv[++i]; }
         else if (a == "--ppm") { need(1); outPpm = argv[++i]; }
         else { std::fprintf(stderr, "rt_render: unknown option %s\n", a.c_str()); return 2; }
     }
     if (!haveGeometry && rt_scene_push_demo(scene) != RT_OK) return die("demo scene", nullptr);
     if (spp < 1) { std::fprintf(stderr, "rt_render: --spp must be >= 1\n"); return 2; }
+    if (framesPerCall < 1) { std::fprintf(stderr, "rt_render: --frames-per-call must be >= 1\n"); return 2; }
 
     // tree.build(scene.meshes); tree.buildLinerTree();   main.cpp:113-115
     const int64_t n = rt_scene_triangle_count(scene);
@@ -146,19 +156,36 @@ int main(int argc, char **argv) {
     uint32_t state = seed;
     for (int f = 0; f < spp; f++) ro[(size_t)f] = rt_rand_origin(&state);                                         // main.cpp:149
     t0 = std::chrono::steady_clock::now();
-    const int batch = 64;       // the path kernel renders up to 64 frames per launch
-    for (int first = 1; first <= spp; first += batch) {
+    const int batch = framesPerCall;
+    const size_t imageBytes = (size_t)W * H * 3 * sizeof(float);
+    float *shown[2] = {nullptr, nullptr};       // what a window would display: the image of the call before the one being traced
+    if (show) {
+        for (float *&p : shown) { p = (float *)rt_host_alloc(imageBytes); if (!p) return die("rt_host_alloc", nullptr); }
+    }
+    int calls = 0;
+    double shownSum = 0.0;
+    for (int first = 1; first <= spp; first += batch, calls++) {
         const int cnt = (spp - first + 1 < batch) ? spp - first + 1 : batch;
         if (rt_render_frames(ctx, first, cnt, ro.data() + (first - 1)) != RT_OK) return die("rt_render_frames", ctx);
+        if (show) {
+            if (rt_read_wait(ctx) != RT_OK) return die("rt_read_wait", ctx);            // the previous call's image is there ...
+            if (calls > 0) shownSum += shown[(calls - 1) & 1][((size_t)(H / 2) * W + W / 2) * 3];  // ... a window would draw it now
+            if (rt_read_mean_async(ctx, shown[calls & 1]) != RT_OK) return die("rt_read_mean_async", ctx);
+        }
     }
+    if (show && rt_read_wait(ctx) != RT_OK) return die("rt_read_wait", ctx);
     if (rt_synchronize(ctx) != RT_OK) return die("rt_synchronize", ctx);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     RtStats st;
     if (rt_get_stats(ctx, &st) != RT_OK) return die("rt_get_stats", ctx);
     std::printf("LoopNum: %d  frame time: %.3f ms  rays: %llu  %.1f Mrays/s\n", spp, ms / spp, (unsigned long long)st.rays, (double)st.rays / ms * 1e-3);
 
+    if (show) std::printf("shown: %d images, centre pixel of the last one %.6f\n", calls, (double)shown[(calls - 1) & 1][((size_t)(H / 2) * W + W / 2) * 3]);
+    (void)shownSum;
     std::vector<float> rgb((size_t)W * H * 3);
     if (rt_read_mean(ctx, rgb.data()) != RT_OK) return die("rt_read_mean", ctx);
+    if (show && std::memcmp(rgb.data(), shown[(calls - 1) & 1], imageBytes) != 0) { std::fprintf(stderr, "rt_render: the last image shown differs from the final image\n"); return 1; }
+    for (float *p : shown) rt_host_free(p);
     if (!outPfm.empty()) {          // PFM stores rows bottom to top, as the accumulation buffer does
         FILE *f = std::fopen(outPfm.c_str(), "wb");
         if (!f) { std::perror(outPfm.c_str()); return 1; }

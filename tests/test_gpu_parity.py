@@ -866,6 +866,13 @@ def test_cxx_host_program_matches_python_path(tmp_path):
     assert np.array_equal(got, r.read_mean())
     ppm = open(tmp_path / "img.ppm", "rb").read()
     assert ppm.startswith(b"P6\n%d %d\n255\n" % (W, H)) and len(ppm) == len(b"P6\n%d %d\n255\n" % (W, H)) + W * H * 3
+    # the reference's own loop: one frame per call, the image fetched after every call (--show: the
+    # copy of one call's image overlaps the tracing of the next); same final image
+    shown = subprocess.check_output([exe, "--demo", "--size", str(W), str(H), "--spp", str(spp), "--frames-per-call", "1", "--show",
+                                     "--out", str(tmp_path / "shown.pfm")]).decode()
+    assert "shown: %d images" % spp in shown
+    raw2 = open(tmp_path / "shown.pfm", "rb").read()
+    assert np.array_equal(np.frombuffer(raw2[len(header):], dtype="<f4").reshape(H, W, 3), got)
     # --texture: a binary PPM sampled at the model's vt coordinates (RtOptions.albedo_texture)
     _globe_obj(str(tmp_path / "globe.obj"))
     image = np.random.default_rng(3).integers(0, 256, (9, 14, 3)).astype(np.uint8)
