@@ -91,3 +91,19 @@ def test_index_of_tiny_scenes(monkeypatch):
         _check(scenes.random_triangles(n, 11 + n), False, monkeypatch)
     nodes, info = rt.index_build_host(scenes.random_triangles(1, 1))
     assert info["nodes"] == 0           # one triangle: the root is the leaf
+
+
+def test_builders_do_not_depend_on_the_number_of_host_threads(monkeypatch):
+    """RT_AMD_HOST_THREADS bounds the worker threads of the host-side builders (a job with one process
+    per GPU shares the host between its ranks); the reference tree and the search index must come
+    out byte for byte the same with one thread and with many."""
+    sc = rt.Scene()
+    sc.push_synthetic(0, 7, 1, 12345)                       # 327 700 triangles: every parallel path is taken
+    t = sc.triangles()
+    out = {}
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("RT_AMD_HOST_THREADS", threads)
+        tris, nodes = rt.bvh_build(t)
+        index, info = rt.index_build_host(tris)
+        out[threads] = (tris.tobytes(), nodes.tobytes(), index.tobytes(), info["levels"])
+    assert out["1"] == out["3"] == out["16"]
