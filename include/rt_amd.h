@@ -37,6 +37,9 @@ extern "C" {
 #define RT_MAX_SPHERES 10   /* uniform Sphere sphere[10], frag:143 */
 #define RT_SOBOL_WORDS 512  /* uniform uint V[512], frag:81 */
 #define RT_MAX_BOUNCES 8    /* 16 Sobol dimensions / 2 per bounce, frag:100-104 */
+#define RT_MAX_TRIANGLES 50000000   /* per scene: every per-triangle record array on the GPU stays below 4 GiB, so the
+                                       kernels address records with 32-bit offsets (the reference's own BVH texture
+                                       cannot express more than 4 194 304 triangles, ObjectTexture.h:152-154) */
 
 /* class Triangle, BVH.h:26-33 (144 bytes, same field order). */
 typedef struct RtTriangle {

@@ -55,6 +55,7 @@ lib = C.CDLL(LIB_PATH)
 RT_MAX_SPHERES = 10
 RT_SOBOL_WORDS = 512
 RT_MAX_BOUNCES = 8
+RT_MAX_TRIANGLES = 50000000
 RT_NOALLOC_MAX_RAYS = 262144
 RT_SWEEP_MAX_TRIANGLES = 16384
 PIPELINE_WAVEFRONT = 0

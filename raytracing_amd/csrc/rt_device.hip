@@ -951,7 +951,8 @@ int build_device_scene(RtContext *ctx, const RtTriangle *tris, int64_t n, const 
                        std::vector<float4> &hNodes, std::vector<float4> &hTris, std::vector<float4> &hMats, SceneD &S,
                        bool &boxesExact) {
     if (n <= 0 || m != 2 * n - 1) return fail(ctx, RT_E_INVALID, "scene upload: need n >= 1 triangles and exactly 2n-1 nodes");
-    if (n > (int64_t)0x7FFFFFF0) return fail(ctx, RT_E_INVALID, "scene upload: too many triangles");
+    if (n > (int64_t)RT_MAX_TRIANGLES) return fail(ctx, RT_E_INVALID, "scene upload: more than RT_MAX_TRIANGLES (50 000 000) triangles");
+    static_assert((uint64_t)RT_MAX_TRIANGLES * 80u < ((uint64_t)1 << 32), "the largest per-triangle record (80 bytes) must stay below 4 GiB");
     std::vector<uint32_t> interiorIdx((size_t)m, REF_NONE);
     std::vector<int32_t> depth((size_t)m, 0);
     std::vector<uint8_t> referenced((size_t)m, 0);

@@ -94,7 +94,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
     // The triangle part runs for every lane (a lane without a triangle reads record 0 and drops the
     // result): no lane-dependent branch, and every value below is defined on one path only.
     const bool triHit = tri != REF_NONE;
-    const float4 *m = S.mats + (size_t)(triHit ? tri : 0u) * 5;
+    const float4 *m = RT_REC(S.mats, triHit ? tri : 0u, 80u);
     const float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4];
     vec3 pos = rtm::along(p.o, tTri, p.d);                                      // frag:458
     vec3 nrm = rtm::mk(m2.y, m2.z, m2.w);                                       // frag:296-300, precomputed

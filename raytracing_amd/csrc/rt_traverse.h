@@ -13,6 +13,13 @@
 namespace rtd {
 
 constexpr float HIT_MIN_INIT = 100000.0f;   // frag:633,689
+
+// Record `i` of an array of `bytes`-byte records: a 32-bit byte offset from the (wave-uniform) base,
+// so that the load takes the base from scalar registers and one vector register of offset instead
+// of a 64-bit vector address (two to three vector instructions less per record; measured +0.4 %
+// on 1.3M triangles, +1.7 % on 262k at 4K).  Valid because rt_scene_upload refuses scenes whose
+// record arrays would reach 4 GiB (RT_MAX_TRIANGLES).
+#define RT_REC(base, i, bytes) ((const float4 *)((const char *)(base) + (uint32_t)((uint32_t)(i) * (bytes))))
 constexpr int FAST_QUEUE_ENTRIES = 6;        // FastTrav::PEND_MAX: LDS entries per lane ahead of the deferred nodes
 
 // IntersectBound, frag:309-331, evaluated without early exits (the values computed after a
@@ -113,7 +120,7 @@ struct Trav {
 
     // cur is an interior node: test both children, descend / defer / pop (frag:386-420)
     __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *stack, const int stride, uint32_t &nNode) {
-        const float4 *rec = S.nodes + (size_t)cur * 4;
+        const float4 *rec = RT_REC(S.nodes, cur, 64u);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
         float lnx, lny, lnz, rnx, rny, rnz;
         bool passL = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, nx, ny, nz, lnx, lny, lnz);
@@ -144,7 +151,7 @@ struct Trav {
     // cur is a leaf: test its triangle, keep it if closer (frag:390-403), then pop
     __device__ __forceinline__ void leaf_step(const SceneD &S, const uint32_t *stack, const int stride, uint32_t &nTri) {
         const uint32_t ti = cur & ~LEAF_BIT;
-        const float4 *rec = S.tris + (size_t)ti * TRI_RECORD;
+        const float4 *rec = RT_REC(S.tris, ti, 48u);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const float dis = triangle_test(q0, q1, q2, o, d);
         if (COUNT) nTri++;
@@ -284,7 +291,7 @@ struct FastTrav {
     // A child counts as hit unless its box provably is not: max(entry, 0) > min(exit, hitCull)
     // (a NaN entry counts as 0, a NaN exit as hitCull).
     __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t &nNode) {
-        const float4 *rec = S.anodes + (size_t)cur * 4;
+        const float4 *rec = RT_REC(S.anodes, cur, 64u);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
         const float Ax = q0.w * inv.x, Bx = (q0.x - o.x) * inv.x;
         const float Ay = q3.z * inv.y, By = (q0.y - o.y) * inv.y;
@@ -351,7 +358,7 @@ struct FastTrav {
     // tests one queued triangle with the reference's hitTriangle arithmetic
     __device__ __forceinline__ void test_step(const SceneD &S, const uint32_t *col, const int stride, uint32_t &nTri) {
         const uint32_t ti = unqueue_triangle(col, stride);
-        const float4 *rec = S.tris + (size_t)ti * TRI_RECORD;
+        const float4 *rec = RT_REC(S.tris, ti, 48u);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const float dis = triangle_test(q0, q1, q2, o, d);
         if (COUNT) nTri++;
@@ -375,7 +382,7 @@ struct FastTrav {
 // implies a pass at every ancestor: testing the leaf's own box (the min/max of the triangle's
 // vertices, BVH.h:42-54) is enough.
 __device__ __forceinline__ bool verify_reference_reaches(const SceneD &S, const vec3 o, const vec3 inv, uint32_t tri) {
-    const float4 *rec = S.tris + (size_t)tri * TRI_RECORD;
+    const float4 *rec = RT_REC(S.tris, tri, 48u);
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const float mnx = fminf(fminf(q0.x, q0.w), q1.z), mxx = fmaxf(fmaxf(q0.x, q0.w), q1.z);
     const float mny = fminf(fminf(q0.y, q1.x), q1.w), mxy = fmaxf(fmaxf(q0.y, q1.x), q1.w);

@@ -831,6 +831,10 @@ def test_error_paths():
         r.upload(tris, bad)
     with pytest.raises(rt.RtError, match="2n-1"):
         r.upload(tris, nodes[:-1])
+    # more triangles than the 32-bit record offsets of the kernels can address: refused before anything is read
+    too_many = rt.RT_MAX_TRIANGLES + 1
+    rc = rt.lib.rt_scene_upload(r._h, tris.ctypes.data, too_many, nodes.ctypes.data, 2 * too_many - 1)
+    assert rc == -1 and b"RT_MAX_TRIANGLES" in rt.lib.rt_last_error(r._h)
     r.upload(tris, nodes)
     with pytest.raises(rt.RtError, match="no camera"):
         r.render(1, ro)
