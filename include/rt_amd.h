@@ -428,6 +428,10 @@ int rt_selftest_index_build(const RtTriangle *tris, int64_t n, float scene_max_a
                             int64_t node_capacity, int64_t *node_count, double stats[4]);
 int rt_selftest_sort(float *keys, int32_t *ids, int64_t n);     /* the builder's sort against std::sort */
 int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out);
+/* The two device-wide primitives of the index build on the GPU, on host arrays: a stable radix sort of
+ * n (64-bit key, 32-bit value) pairs by key, in place; the exclusive prefix sums of n 64-bit values, in place. */
+int rt_selftest_device_sort(RtContext *ctx, uint64_t *keys, uint32_t *vals, int64_t n);
+int rt_selftest_device_scan(RtContext *ctx, uint64_t *values, int64_t n);
 int rt_selftest_exact_math(RtContext *ctx, uint64_t mismatches[4]);
 
 const char *rt_last_error(const RtContext *ctx);    /* ctx may be NULL: last error of a call without a context */

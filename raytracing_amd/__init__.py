@@ -174,6 +174,8 @@ _PROTOS = {
     "rt_selftest_arith": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "rt_selftest_index_build": (_int, [_vp, _i64, C.c_float, _vp, _i64, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "rt_selftest_exact_math": (_int, [_vp, C.POINTER(C.c_uint64)]),
+    "rt_selftest_device_sort": (_int, [_vp, _vp, _vp, _i64]),
+    "rt_selftest_device_scan": (_int, [_vp, _vp, _i64]),
     "rt_last_error": (C.c_char_p, [_vp]),
     "rt_version": (C.c_char_p, []),
 }
@@ -510,6 +512,20 @@ class Renderer:
         out = (C.c_uint64 * 4)()
         _check(lib.rt_selftest_exact_math(self._h, out), self._h)
         return [int(v) for v in out]
+
+    def selftest_device_sort(self, keys, vals):
+        """The index build's radix sort on the device: (keys uint64, vals uint32) sorted by key, stable."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        assert k.shape == v.shape and k.ndim == 1
+        _check(lib.rt_selftest_device_sort(self._h, _ptr(k), _ptr(v), k.shape[0]), self._h)
+        return k, v
+
+    def selftest_device_scan(self, values):
+        """The index build's exclusive prefix sum on the device (uint64)."""
+        x = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        _check(lib.rt_selftest_device_scan(self._h, _ptr(x), x.shape[0]), self._h)
+        return x
 
     def selftest_arith(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.float32)

@@ -1983,6 +1983,22 @@ int rt_trace_rays_noalloc(RtContext *ctx, const float *d_origins, const float *d
     return RT_OK;
 }
 
+int rt_selftest_device_sort(RtContext *ctx, uint64_t *keys, uint32_t *vals, int64_t n) {
+    if (!ctx || (n > 0 && (!keys || !vals))) return fail(ctx, RT_E_INVALID, "rt_selftest_device_sort: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = rt::selftest_device_sort(keys, vals, n, ctx->stream, err);
+    return rc == RT_OK ? RT_OK : fail(ctx, rc, "rt_selftest_device_sort: " + err);
+}
+
+int rt_selftest_device_scan(RtContext *ctx, uint64_t *values, int64_t n) {
+    if (!ctx || (n > 0 && !values)) return fail(ctx, RT_E_INVALID, "rt_selftest_device_scan: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = rt::selftest_device_scan(values, n, ctx->stream, err);
+    return rc == RT_OK ? RT_OK : fail(ctx, rc, "rt_selftest_device_scan: " + err);
+}
+
 // Not part of the reference boundary: runs the device's divide / sqrt / fma / sincos on
 // caller data so that a test can compare them with the host's (out has 5*n floats).
 int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n, float *out) {

@@ -23,4 +23,8 @@ struct GpuIndex {
 int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], const float sceneMax[3], float sceneMaxAbs,
                     hipStream_t st, GpuIndex &out, std::string &err);
 
+// Tests: the build's radix sort (stable, in place) and exclusive prefix sum on host arrays.
+int selftest_device_sort(uint64_t *keys, uint32_t *vals, int64_t n, hipStream_t st, std::string &err);
+int selftest_device_scan(uint64_t *values, int64_t n, hipStream_t st, std::string &err);
+
 }  // namespace rt

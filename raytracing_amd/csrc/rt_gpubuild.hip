@@ -3,7 +3,7 @@
 //
 // The host builder (rt_accel.cpp, binned SAH) takes 0.2 s for 1.3M triangles and 1.5 s for 10M.
 // This one builds on the device in a few milliseconds: triangle boxes and 63-bit Morton codes of
-// their centres, a radix sort, agglomerative clustering of neighbours in that order (parallel
+// their centres, a radix sort (rt_devprims.h), agglomerative clustering of neighbours in that order (parallel
 // locally-ordered clustering) into a binary tree, and a level-by-level collapse into the same
 // 4-wide nodes with 8-bit quantised child boxes that the traversal kernels read (rt_accel.h
 // WideNode).  The boxes are grown and quantised with the host builder's formulas, so the search
@@ -14,7 +14,6 @@
 // The reference has no counterpart: its only tree is the median split of BVH.h:188-264, built
 // on the CPU (its author's alternative split, BVH.h:225-256, is rt_bvh_build_sweep).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -23,6 +22,7 @@
 #include <string>
 
 #include "rt_accel.h"
+#include "rt_devprims.h"
 #include "rt_gpubuild.h"
 
 namespace rt {
@@ -308,9 +308,15 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
         out.rootRef = LEAF | 0u; out.wideDepth = 0; out.wideCount = 0; out.wide = nullptr;
         goto done;
     }
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 64, st));
+    // stable radix sort of (Morton key, triangle) and, below, the prefix sums of the clustering rounds
+    // (rt_devprims.h); one scratch buffer serves both
+    tmpBytes = std::max(rtp::sort_scratch_bytes((uint32_t)N), rtp::scan_scratch_bytes<uint64_t>((uint32_t)N));
     GB_TRY(hipMalloc(&tmp, std::max<size_t>(tmpBytes, 16)));
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, keys, keysSorted, ids, idsSorted, N, 0, 64, st));
+    GB_TRY(rtp::radix_sort_pairs(keys, keysSorted, ids, idsSorted, (uint32_t)N, tmp, st));
+    // after its eight passes the sorted pairs are back in the buffers they came from: those are
+    // the sorted ones from here on, the others are free
+    std::swap(keys, keysSorted);
+    std::swap(ids, idsSorted);
     GB_TRY(hipMalloc(&left, nInt * 4)); GB_TRY(hipMalloc(&right, nInt * 4));
     GB_TRY(hipMalloc(&nodeBox, nInt * sizeof(Box6)));
     GB_TRY(hipMalloc(&counters, (MAX_LEVELS + 4) * 4));
@@ -325,9 +331,6 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
         GB_TRY(hipMalloc(&cbox[0], (size_t)N * sizeof(Box6))); GB_TRY(hipMalloc(&cbox[1], (size_t)N * sizeof(Box6)));
         GB_TRY(hipMalloc(&flags, (size_t)N * 8)); GB_TRY(hipMalloc(&scan, (size_t)N * 8));
         GB_TRY(hipMalloc(&dState, 16));         // clusters left, nodes made
-        size_t scanBytes = 0;
-        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, flags, scan, N, st));
-        if (scanBytes > tmpBytes) { hipFree(tmp); tmp = nullptr; tmpBytes = scanBytes; GB_TRY(hipMalloc(&tmp, tmpBytes)); }
         hipLaunchKernelGGL(k_ploc_init, dim3(blocksN), dim3(BLOCK), 0, st, (uint32_t)N, prim, idsSorted, cl[0], cbox[0]);
         uint32_t count = (uint32_t)N, made = 0;
         int radius = PLOC_RADIUS;
@@ -336,10 +339,9 @@ int build_index_gpu(const float4 *dTris, int64_t n, const float sceneMin[3], con
         for (int round = 0; count > 1u; round++) {
             if (round >= 4096) { err = "GPU index build: clustering did not finish"; rc = RT_E_INVALID; goto done; }
             const int blocks = (int)((count + BLOCK - 1) / BLOCK);
-            size_t sb = tmpBytes;
             hipLaunchKernelGGL(k_ploc_nearest, dim3(blocks), dim3(BLOCK), 0, st, count, radius, cbox[cur], (uint32_t *)keys);     // keys is free after the sort: the neighbour choices
             hipLaunchKernelGGL(k_ploc_flags, dim3(blocks), dim3(BLOCK), 0, st, count, (const uint32_t *)keys, flags);
-            GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, sb, flags, scan, (int)count, st));
+            GB_TRY(rtp::exclusive_sum<uint64_t>(flags, scan, count, tmp, st));
             hipLaunchKernelGGL(k_ploc_merge, dim3(blocks), dim3(BLOCK), 0, st, count, made, (const uint32_t *)keys, flags, scan, cl[cur], cbox[cur],
                                cl[cur ^ 1], cbox[cur ^ 1], left, right, nodeBox, dState);
             uint32_t state[2] = {0, 0};
@@ -382,6 +384,43 @@ done:
     hipFree(left); hipFree(right); hipFree(clB); hipFree(dState); hipFree(counters);
     hipFree(frontier[0]); hipFree(frontier[1]); hipFree(tmp); hipFree(wide);
     hipFree(cbox[0]); hipFree(cbox[1]); hipFree(flags); hipFree(scan);
+    return rc;
+}
+
+// The two device primitives of the build on caller data, for tests: sorts n (key, value) pairs
+// in place (stable), or replaces n values by their exclusive prefix sums.  Host arrays.
+int selftest_device_sort(uint64_t *keys, uint32_t *vals, int64_t n, hipStream_t st, std::string &err) {
+    if (n < 0 || n >= ((int64_t)1 << 28)) { err = "device sort: n out of range"; return RT_E_INVALID; }
+    if (n == 0) return RT_OK;
+    int rc = RT_OK;
+    uint64_t *dk = nullptr, *dk2 = nullptr; uint32_t *dv = nullptr, *dv2 = nullptr; void *tmp = nullptr;
+    GB_TRY(hipMalloc(&dk, (size_t)n * 8)); GB_TRY(hipMalloc(&dk2, (size_t)n * 8));
+    GB_TRY(hipMalloc(&dv, (size_t)n * 4)); GB_TRY(hipMalloc(&dv2, (size_t)n * 4));
+    GB_TRY(hipMalloc(&tmp, rtp::sort_scratch_bytes((uint32_t)n)));
+    GB_TRY(hipMemcpyAsync(dk, keys, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    GB_TRY(hipMemcpyAsync(dv, vals, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    GB_TRY(rtp::radix_sort_pairs(dk, dk2, dv, dv2, (uint32_t)n, tmp, st));
+    GB_TRY(hipMemcpyAsync(keys, dk, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    GB_TRY(hipMemcpyAsync(vals, dv, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    GB_TRY(hipStreamSynchronize(st));
+done:
+    hipFree(dk); hipFree(dk2); hipFree(dv); hipFree(dv2); hipFree(tmp);
+    return rc;
+}
+
+int selftest_device_scan(uint64_t *values, int64_t n, hipStream_t st, std::string &err) {
+    if (n < 0 || n >= ((int64_t)1 << 30)) { err = "device scan: n out of range"; return RT_E_INVALID; }
+    if (n == 0) return RT_OK;
+    int rc = RT_OK;
+    uint64_t *d = nullptr; void *tmp = nullptr;
+    GB_TRY(hipMalloc(&d, (size_t)n * 8));
+    GB_TRY(hipMalloc(&tmp, rtp::scan_scratch_bytes<uint64_t>((uint32_t)n)));
+    GB_TRY(hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    GB_TRY(rtp::exclusive_sum<uint64_t>(d, d, (uint32_t)n, tmp, st));
+    GB_TRY(hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    GB_TRY(hipStreamSynchronize(st));
+done:
+    hipFree(d); hipFree(tmp);
     return rc;
 }
 
