@@ -241,3 +241,100 @@ def test_async_read_shows_frame_n_while_frame_n_plus_one_is_traced():
         assert r.stats()["frames"] == N
     assert r.mean_device_ptr() != 0
     r.close()
+
+
+def test_random_call_sequences_do_not_depend_on_overlap_or_coalescing():
+    """Seeded random sequences of the calls a host makes - render 1..70 frames, read the mean or the
+    sum, statistics, move the camera, change the spheres, switch pipeline or options, reset,
+    restore, trace rays without allocation, read asynchronously - replayed on three contexts:
+    everything on the context's stream (overlap off), overlapped launches, overlapped launches with
+    call coalescing.  Every value a call returns must be the same on all three."""
+    import torch
+    Wc, Hc = 200, 120
+    sc = _hall()
+    tris, nodes = rt.bvh_build(sc.triangles())
+    spheres = sc.spheres()
+    cams = [rt.camera_default(Wc, Hc), rt.camera_from_angles((1.0, 3.0, 9.0), -100.0, -5.0, 40.0, Wc, Hc),
+            rt.camera_from_angles((-4.0, 8.0, 2.0), -30.0, -20.0, 45.0, Wc, Hc)]
+    ro_all = rt.rand_origins(99, 8192)
+    o, d = scenes.random_rays(5000, 2, extent=10.0, axis_aligned_fraction=0.3)
+    do, dd = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    torch.cuda.synchronize()
+
+    def replay(seed, overlap, coalesce):
+        rng = np.random.default_rng(seed)
+        r = rt.Renderer(Wc, Hc)
+        r.upload(tris, nodes)
+        r.set_spheres(spheres)
+        r.set_camera(cams[0])
+        base = dict(overlap=overlap, coalesce=coalesce)
+        opts = dict(base)
+        r.set_options(**opts)
+        dt = torch.zeros(o.shape[0], dtype=torch.float32, device="cuda")
+        di = torch.zeros(o.shape[0], dtype=torch.int32, device="cuda")
+        pinned = r.host_image()
+        torch.cuda.synchronize()
+        frame, log, saved = 0, [], None
+        for step in range(60):
+            op = rng.choice(["render1", "render1", "render1", "render_few", "render_many", "mean", "sum", "stats", "camera", "spheres",
+                             "pipeline", "bounces", "reset", "restore", "trace", "async"])
+            if op.startswith("render"):
+                cnt = 1 if op == "render1" else (int(rng.integers(2, 9)) if op == "render_few" else int(rng.integers(20, 71)))
+                for _ in range(int(rng.integers(1, 6)) if op == "render1" else 1):
+                    r.render(frame + 1, ro_all[frame:frame + cnt])
+                    frame += cnt
+            elif op == "mean":
+                log.append(("mean", r.read_mean()))
+            elif op == "sum":
+                log.append(("sum", r.read_sum()))
+            elif op == "stats":
+                st = r.stats()
+                log.append(("stats", (st["frames"], st["rays"])))
+            elif op == "camera":
+                r.set_camera(cams[int(rng.integers(0, 3))])
+            elif op == "spheres":
+                r.set_spheres(spheres[:int(rng.integers(0, len(spheres) + 1))])
+            elif op == "pipeline":
+                opts = dict(base, pipeline=int(rng.choice([rt.PIPELINE_PERSISTENT, rt.PIPELINE_PERSISTENT, rt.PIPELINE_WAVEFRONT, rt.PIPELINE_MEGAKERNEL])),
+                            max_bounces=opts.get("max_bounces", 4))
+                r.set_options(**opts)
+            elif op == "bounces":
+                opts = dict(opts, max_bounces=int(rng.integers(1, 9)))
+                r.set_options(**opts)
+            elif op == "reset":
+                r.reset()
+                frame = 0
+            elif op == "restore":
+                if saved is None:
+                    saved = (r.read_mean(), r.read_sum(), frame)
+                else:
+                    r.restore(saved[0], saved[1], saved[2])
+                    frame = saved[2]
+                    saved = None
+            elif op == "trace":
+                r.trace_rays_noalloc(do.data_ptr(), dd.data_ptr(), o.shape[0], dt.data_ptr(), di.data_ptr())
+            elif op == "async":
+                r.read_mean_async(pinned)
+                if rng.integers(0, 2):
+                    r.render(frame + 1, ro_all[frame:frame + 1])      # traced beside the copy, added after it
+                    frame += 1
+                r.read_wait()
+                log.append(("async", pinned.copy()))
+        log.append(("final", r.read_mean()))
+        r.synchronize()
+        log.append(("trace", (dt.cpu().numpy().copy(), di.cpu().numpy().copy())))
+        r.close()
+        return log
+
+    for seed in range(1, 11):
+        logs = [replay(seed, False, False), replay(seed, True, False), replay(seed, True, True)]
+        assert len(logs[0]) == len(logs[1]) == len(logs[2])
+        for a, b, c in zip(*logs):
+            assert a[0] == b[0] == c[0]
+            for x in (b, c):
+                if isinstance(a[1], np.ndarray):
+                    assert _eq(a[1], x[1]), (seed, a[0])
+                elif a[0] == "trace":
+                    assert np.array_equal(a[1][0], x[1][0]) and np.array_equal(a[1][1], x[1][1]), seed
+                else:
+                    assert a[1] == x[1], (seed, a[0])
