@@ -417,6 +417,16 @@ __global__ void k_sobol_table(const BatchD B, const int maxBounces, const uint32
     table[t] = (float)acc * (1.0f / 4294967296.0f);
 }
 
+// The arguments of k_paths as the kernel-argument segment holds them (each argument at the next
+// offset of its alignment, i.e. the layout of this struct).  The part of the loop that runs once in
+// several iterations - shading, new camera rays, the start of the next ray - reads what it needs
+// of the scene, the frame and the batch from there at the point of use (scalar loads), so that
+// these values do not sit in scalar registers across the traversal and get spilled around it.
+struct PathsArgs {
+    SceneD S; FrameD F; BatchD B;
+    const float *sob; uint32_t *workHead; float *cur; WorkCounters *wc;
+};
+
 // Whole paths in one launch: persistent waves, each lane owns one path at a time and runs it
 // from the camera ray to its end (generate, extend, shade, extend, ... as frag:677-689 +
 // frag:617-675 do per pixel), then takes the next (frame, pixel) item.  Several frames are in
@@ -508,16 +518,21 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
 #ifdef RT_EXP_PROFILE
             xGo += 1ull + ((unsigned long long)nFin << 32);
 #endif
+            // scene, frame and batch as the kernel-argument segment holds them, read where they are used
+            // (the empty asm keeps the compiler from merging these loads with the ones at kernel entry)
+            const __attribute__((address_space(4))) PathsArgs *ka = (const __attribute__((address_space(4))) PathsArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const auto &Sf = ka->S; const auto &Ff = ka->F; const auto &Bf = ka->B;
             if constexpr (FAST) {
                 bool exact = false;
                 if (fin) {
-                    exact = tv.tie || !tv.usable(S);
-                    if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(S, tv.o, tv.inv, tv.best);
+                    exact = tv.tie || !tv.usable(Sf);
+                    if (!exact && tv.best != REF_NONE) exact = !verify_reference_reaches(Sf, tv.o, tv.inv, tv.best);
 #ifdef RT_EXP_TIMELINE
                     // experiment builds: why rays are traced again (the work counters are free when COUNT is off)
                     if (!COUNT && exact) {
                         if (tv.tie) atomicAdd(&wc->node_tests, 1ull);
-                        else if (!tv.usable(S)) atomicAdd(&wc->tri_tests, 1ull);
+                        else if (!tv.usable(Sf)) atomicAdd(&wc->tri_tests, 1ull);
                         else atomicAdd(&wc->tri_hits, 1ull);
                         tlRetrace++;
                     }
@@ -538,18 +553,18 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 cRays++;
                 if (COUNT && tv.best != REF_NONE) cHit++;
                 const uint32_t px = pix & maskX, py = (pix >> B.bitsX) & maskY, slot = pix >> shiftSlot;
-                const int si = ((int)slot * F.maxBounces + bounce) * 2;
+                const int si = ((int)slot * Ff.maxBounces + bounce) * 2;
                 Path p;
                 p.o = tv.o; p.d = tv.d; p.thr = thr; p.seed = seed;
                 vec3 sample;
-                const bool goOn = shade_hit<EXT>(F, S, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], px, py, sample);
+                const bool goOn = shade_hit<EXT>(Ff, Sf, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], px, py, sample);
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
                     nextO = p.o; nextD = p.d; startRay = true;
                 } else {
                     // a launch holds at most 2 GiB of sample images (paths_frames_cap), so the index fits 32 bits
-                    float *dst = cur + (slot * (uint32_t)frameFloats + (py * (uint32_t)F.width + px) * 3u);
+                    float *dst = cur + (slot * (uint32_t)frameFloats + (py * (uint32_t)Ff.width + px) * 3u);
                     dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
                     have = false;
                 }
@@ -607,9 +622,9 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 }
                 if (give == nFree) break;
             }
-            if (gotItem && iPx < (uint32_t)F.width && iPy < (uint32_t)F.height) {
+            if (gotItem && iPx < (uint32_t)Ff.width && iPy < (uint32_t)Ff.height) {
                 Path p; float uvx, uvy;
-                generate_path(F, B.randOrigin[iSlot], iPx, iPy, p, uvx, uvy);
+                generate_path(Ff, Bf.randOrigin[iSlot], iPx, iPy, p, uvx, uvy);
                 thr = p.thr; seed = p.seed; bounce = 0;
                 pix = iPx | (iPy << B.bitsX) | (iSlot << shiftSlot);
                 nextO = p.o; nextD = p.d; startRay = true;
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             }
             // continued and new paths start their rays together
             if (startRay) {
-                if constexpr (FAST) tv.begin(S, stack, PATHS_BLOCK, nextO, nextD, cNode); else tv.begin(S, nextO, nextD, cNode);
+                if constexpr (FAST) tv.begin(Sf, stack, PATHS_BLOCK, nextO, nextD, cNode); else tv.begin(S, nextO, nextD, cNode);
             }
             {   // the value is wave uniform; saying so keeps it in scalar registers across the loop
                 const unsigned long long m = ballot64(have);

@@ -57,7 +57,8 @@ struct Path {
 };
 
 // hitSphere, frag:281-293
-__device__ __forceinline__ float sphere_test(const RtSphere &s, const vec3 o, const vec3 d) {
+template <typename SphereT>
+__device__ __forceinline__ float sphere_test(const SphereT &s, const vec3 o, const vec3 d) {
     const vec3 oc = rtm::sub(o, rtm::mk(s.center[0], s.center[1], s.center[2]));
     const float a = rtm::dot(d, d);
     const float b = 2.0f * rtm::dot(oc, d);
@@ -87,8 +88,10 @@ __host__ __device__ __forceinline__ void tangent_frame(const vec3 nrm, vec3 &tan
 // normals) and RtOptions.albedo_texture (S.texels set: diffuse albedo times a texel); kernels
 // that offer them are separate instantiations, so the default ones pay neither registers nor
 // branches for them.
-template <bool EXT = false>
-__device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path &p, float tTri, uint32_t tri,
+// FrameT / SceneT: FrameD / SceneD, possibly qualified with an address space (the path kernel reads
+// them from the kernel-argument segment at the point of use instead of holding them in registers).
+template <bool EXT = false, typename FrameT = FrameD, typename SceneT = SceneD>
+__device__ __forceinline__ bool shade_hit(const FrameT &F, const SceneT &S, Path &p, float tTri, uint32_t tri,
                                           int bounce, float sobU, float sobV, uint32_t pixX, uint32_t pixY, vec3 &sample) {
     sample = rtm::mk(0.0f, 0.0f, 0.0f);
     // The triangle part runs for every lane (a lane without a triangle reads record 0 and drops the
@@ -165,7 +168,7 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
     bool hit = triHit && tTri > 0.0f && tTri < HIT_MIN_INIT;                    // frag:562-565
     float hitMin = hit ? tTri : HIT_MIN_INIT;
     for (int i = 0; i < F.sphereNum; i++) {                                     // frag:570-614
-        const RtSphere &s = F.sph[i];
+        const auto &s = F.sph[i];
         const float dis = sphere_test(s, p.o, p.d);
         if (dis > 0.0f && dis < hitMin) {
             hitMin = dis;
@@ -231,7 +234,8 @@ __device__ __forceinline__ bool shade_hit(const FrameD &F, const SceneD &S, Path
 }
 
 // frag:677-689: seed and camera ray of pixel (px,py)
-__device__ __forceinline__ void generate_path(const FrameD &F, float randOrigin, uint32_t px, uint32_t py,
+template <typename FrameT>
+__device__ __forceinline__ void generate_path(const FrameT &F, float randOrigin, uint32_t px, uint32_t py,
                                               Path &p, float &uvx, float &uvy) {
     uvx = rtm::pixel_coord(px, (float)F.width);
     uvy = rtm::pixel_coord(py, (float)F.height);

@@ -228,7 +228,8 @@ struct FastTrav {
 
     // rays this search may be used for: finite 1/d and an origin within the range the growth
     // of the index boxes was sized for
-    __device__ __forceinline__ bool usable(const SceneD &S) const {
+    template <typename SceneT>
+    __device__ __forceinline__ bool usable(const SceneT &S) const {
         const float oM = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
         return finite3(inv) && (oM <= S.originLimit);
     }
@@ -260,7 +261,8 @@ struct FastTrav {
         return v;
     }
 
-    __device__ __forceinline__ void begin(const SceneD &S, uint32_t *col, const int stride, const vec3 o_, const vec3 d_, uint32_t &nNode) {
+    template <typename SceneT>
+    __device__ __forceinline__ void begin(const SceneT &S, uint32_t *col, const int stride, const vec3 o_, const vec3 d_, uint32_t &nNode) {
         o = o_; d = d_;
         inv = rtm::recip3_exact(d);
         hitMin = HIT_MIN_INIT;
@@ -381,7 +383,8 @@ struct FastTrav {
 // <= every other axis' exit distance and all exit distances are > 0, so a pass at the leaf
 // implies a pass at every ancestor: testing the leaf's own box (the min/max of the triangle's
 // vertices, BVH.h:42-54) is enough.
-__device__ __forceinline__ bool verify_reference_reaches(const SceneD &S, const vec3 o, const vec3 inv, uint32_t tri) {
+template <typename SceneT>
+__device__ __forceinline__ bool verify_reference_reaches(const SceneT &S, const vec3 o, const vec3 inv, uint32_t tri) {
     const float4 *rec = RT_REC(S.tris, tri, 48u);
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const float mnx = fminf(fminf(q0.x, q0.w), q1.z), mxx = fmaxf(fmaxf(q0.x, q0.w), q1.z);
