@@ -650,6 +650,10 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             const bool step = tv.can_step();
 #ifdef RT_EXP_PROFILE
             { const unsigned long long ms = ballot64(step); if (ms) xNode += 1ull + ((unsigned long long)__popcll(ms) << 32); }
+#ifdef RT_EXP_TOPK
+            // node steps at the first RT_EXP_TOPK nodes of the index (reported in place of the test blocks)
+            { const unsigned long long mt = ballot64(step && tv.cur < (uint32_t)(RT_EXP_TOPK)); xTest += (mt ? 1ull : 0ull) + ((unsigned long long)__popcll(mt) << 32); }
+#endif
 #endif
             if (step) tv.node_step(S, stack, PATHS_BLOCK, ovf, cNode);
             // wants_test() and can_step() of every lane, from three compares and scalar logic
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             const unsigned long long waiting = mPend & (mNone | mFull);
             const unsigned long long stepping = ~(mNone | mFull);
             if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
-#ifdef RT_EXP_PROFILE
+#if defined(RT_EXP_PROFILE) && !defined(RT_EXP_TOPK)
                 xTest += 1ull + ((unsigned long long)__popcll(ballot64(tv.npend > 0)) << 32);
 #endif
                 if (tv.npend > 0) tv.test_step(S, stack, PATHS_BLOCK, cTri);

@@ -10,14 +10,18 @@ finish block executions and the lanes active in each).  Needs a library built wi
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracing_amd as rt
-sc = rt.Scene(); sc.push_synthetic(0, 8, 1, 12345)
-r = rt.make_renderer(sc, 1920, 1080, 0, max_bounces=4, pipeline=2)
+# arguments: [copies of the model] [bounces] [index build mode: 0 host, 1 GPU, 2 by size]
+copies = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+bounces = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+sc = rt.Scene(); sc.push_synthetic(0, 8, copies, 12345)
+r = rt.make_renderer(sc, 1920, 1080, 0, max_bounces=bounces, pipeline=2, index_build=int(sys.argv[3]) if len(sys.argv) > 3 else 2)
+print("index nodes", r.scene_info()["index_nodes"] if hasattr(r, "scene_info") else "?")
 ro = rt.rand_origins(20221003, 8)
 r.render(1, ro); r.synchronize()
 st = r.stats()
 rays = st["rays"]
 def split(v): return v & 0xFFFFFFFF, v >> 32
-for name, key in (("iterations", "node_tests"), ("node blocks", "tri_tests"), ("test blocks", "tri_hits"), ("go blocks", "retraced")):
+for name, key in (("iterations", "node_tests"), ("node blocks", "tri_tests"), ("test blocks (top-node steps in an RT_EXP_TOPK build)", "tri_hits"), ("go blocks", "retraced")):
     n, lanes = split(st[key])
-    print(f"{name:12s} count {n:10d}  lanes {lanes:12d}  lanes/block {lanes / max(n, 1):5.1f}  blocks per ray {n / rays:.4f}  lane-steps per ray {lanes / rays:.2f}")
+    print(f"{name:22.22s} count {n:10d}  lanes {lanes:12d}  lanes/block {lanes / max(n, 1):5.1f}  blocks per ray {n / rays:.4f}  lane-steps per ray {lanes / rays:.2f}")
 print("rays", rays)
