@@ -449,11 +449,6 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
     uint32_t *stack = lds_dyn + threadIdx.x;
     uint32_t *ovf = FAST ? S.aovf + (size_t)blockIdx.x * PATHS_BLOCK + threadIdx.x : nullptr;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t tilesX = (uint32_t)(F.width + 7) >> 3, tilesY = (uint32_t)(F.height + 7) >> 3;
-    const uint32_t framePix = tilesX * tilesY * 64u;
-    const uint32_t total = framePix * (uint32_t)B.nframes;
-    const size_t frameFloats = (size_t)F.width * (size_t)F.height * 3;
-    const uint32_t nWaves = gridDim.x * (PATHS_BLOCK / 64);
 
     uint32_t cRays = 0, cNode = 0, cTri = 0, cHit = 0;
 #ifdef RT_EXP_TIMELINE
@@ -467,8 +462,6 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
     bool have = false;
     unsigned long long haveMask = 0ull;                 // wave-uniform: the lanes with `have` set (changes in the finish block only)
     uint32_t pix = 0;                                   // px | py << bitsX | frame slot << (bitsX + bitsY)
-    const uint32_t maskX = (1u << B.bitsX) - 1u, maskY = (1u << B.bitsY) - 1u;
-    const int shiftSlot = B.bitsX + B.bitsY;
     int bounce = 0;
     vec3 thr = rtm::mk(0.0f, 0.0f, 0.0f);
     uint32_t seed = 0;
@@ -476,8 +469,12 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
     uint32_t cSlot = 0, cTy = 0, cTx = 0, cLane = 0;    // wave-uniform: where item cNext lies (frame slot, tile row/column, pixel of the 8x8 tile)
     // first chunk: a quarter of a wave's share of the batch, 64..256 items (a one-frame launch has
     // only ~290 items per wave; handing out 256 at once leaves nothing to balance with)
-    uint32_t chunk = (total / (4u * nWaves)) & ~63u;
-    chunk = chunk < 64u ? 64u : (chunk > 256u ? 256u : chunk);
+    uint32_t chunk;
+    {
+        const uint32_t total0 = (((uint32_t)(F.width + 7) >> 3) * ((uint32_t)(F.height + 7) >> 3) * 64u) * (uint32_t)B.nframes;
+        chunk = (total0 / (4u * (gridDim.x * (PATHS_BLOCK / 64)))) & ~63u;
+        chunk = chunk < 64u ? 64u : (chunk > 256u ? 256u : chunk);
+    }
     bool exhausted = false;                             // wave-uniform: the item counter has passed `total`
 #ifdef RT_EXP_PROFILE
     unsigned long long xIter = 0, xNode = 0, xTest = 0, xGo = 0;
@@ -523,6 +520,16 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             const __attribute__((address_space(4))) PathsArgs *ka = (const __attribute__((address_space(4))) PathsArgs *)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             const auto &Sf = ka->S; const auto &Ff = ka->F; const auto &Bf = ka->B;
+            // what only this block needs of the image and the batch is worked out here from those arguments
+            // (a few scalar instructions once in several iterations) instead of living in registers across the traversal
+            const uint32_t tilesX = (uint32_t)(Ff.width + 7) >> 3, tilesY = (uint32_t)(Ff.height + 7) >> 3;
+            const uint32_t framePix = tilesX * tilesY * 64u;
+            const uint32_t total = framePix * (uint32_t)Bf.nframes;
+            const uint32_t frameFloats = (uint32_t)Ff.width * (uint32_t)Ff.height * 3u;     // a launch holds at most 2 GiB of sample images (paths_frames_cap)
+            const uint32_t nWaves = gridDim.x * (PATHS_BLOCK / 64);
+            const int bitsX = Bf.bitsX, bitsY = Bf.bitsY, shiftSlot = bitsX + bitsY;
+            const uint32_t maskX = (1u << bitsX) - 1u, maskY = (1u << bitsY) - 1u;
+            const float *sobF = ka->sob; uint32_t *workHeadF = ka->workHead; float *curF = ka->cur; WorkCounters *wcF = ka->wc;
             if constexpr (FAST) {
                 bool exact = false;
                 if (fin) {
@@ -531,9 +538,9 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
 #ifdef RT_EXP_TIMELINE
                     // experiment builds: why rays are traced again (the work counters are free when COUNT is off)
                     if (!COUNT && exact) {
-                        if (tv.tie) atomicAdd(&wc->node_tests, 1ull);
-                        else if (!tv.usable(Sf)) atomicAdd(&wc->tri_tests, 1ull);
-                        else atomicAdd(&wc->tri_hits, 1ull);
+                        if (tv.tie) atomicAdd(&wcF->node_tests, 1ull);
+                        else if (!tv.usable(Sf)) atomicAdd(&wcF->tri_tests, 1ull);
+                        else atomicAdd(&wcF->tri_hits, 1ull);
                         tlRetrace++;
                     }
 #endif
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                         float t; uint32_t tri;
                         closest_triangle<true, COUNT>(S, tv.o, tv.d, ovf + (size_t)S.aovfRetrace * S.aovfStride, (int)S.aovfStride, t, tri, cNode, cTri);
                         tv.hitMin = t; tv.best = tri;
-                        atomicAdd(&wc->retraced, 1ull);
+                        atomicAdd(&wcF->retraced, 1ull);
                     }
                 }
             }
@@ -552,19 +559,18 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             if (fin) {
                 cRays++;
                 if (COUNT && tv.best != REF_NONE) cHit++;
-                const uint32_t px = pix & maskX, py = (pix >> B.bitsX) & maskY, slot = pix >> shiftSlot;
+                const uint32_t px = pix & maskX, py = (pix >> bitsX) & maskY, slot = pix >> shiftSlot;
                 const int si = ((int)slot * Ff.maxBounces + bounce) * 2;
                 Path p;
                 p.o = tv.o; p.d = tv.d; p.thr = thr; p.seed = seed;
                 vec3 sample;
-                const bool goOn = shade_hit<EXT>(Ff, Sf, p, tv.hitMin, tv.best, bounce, sob[si], sob[si + 1], px, py, sample);
+                const bool goOn = shade_hit<EXT>(Ff, Sf, p, tv.hitMin, tv.best, bounce, sobF[si], sobF[si + 1], px, py, sample);
                 if (goOn) {
                     bounce++;
                     thr = p.thr; seed = p.seed;
                     nextO = p.o; nextD = p.d; startRay = true;
                 } else {
-                    // a launch holds at most 2 GiB of sample images (paths_frames_cap), so the index fits 32 bits
-                    float *dst = cur + (slot * (uint32_t)frameFloats + (py * (uint32_t)Ff.width + px) * 3u);
+                    float *dst = curF + (slot * frameFloats + (py * (uint32_t)Ff.width + px) * 3u);
                     dst[0] = sample.x; dst[1] = sample.y; dst[2] = sample.z;
                     have = false;
                 }
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 if (cNext >= cEnd) {
                     uint32_t base = 0;
                     const int leader = __ffsll((long long)freeMask) - 1;
-                    if ((int)lane == leader) base = atomicAdd(workHead, chunk);
+                    if ((int)lane == leader) base = atomicAdd(workHeadF, chunk);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // scalar: the chunk bookkeeping stays wave uniform
                     if (base >= total) {
                         exhausted = true;
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 Path p; float uvx, uvy;
                 generate_path(Ff, Bf.randOrigin[iSlot], iPx, iPy, p, uvx, uvy);
                 thr = p.thr; seed = p.seed; bounce = 0;
-                pix = iPx | (iPy << B.bitsX) | (iSlot << shiftSlot);
+                pix = iPx | (iPy << bitsX) | (iSlot << shiftSlot);
                 nextO = p.o; nextD = p.d; startRay = true;
                 have = true;
             }
@@ -787,7 +793,7 @@ struct RtContext {
     int texW = 0, texH = 0;
     float4 *dANodes = nullptr;                                  // search index: nodes
     uint32_t *dAOvf[NSLOT] = {};                               // overflow of the deferred-node stack, one per launch slot
-    int accelLdsEntries = 16;
+    int accelLdsEntries = 0;    // RT_AMD_ACCEL_LDS_ENTRIES; 0 = by the path kernel's occupancy (index_lds_entries_for)
     int64_t nTris = 0, nInterior = 0, nIndexNodes = 0;
     int indexStackNeed = 0;
     bool boxesExact = true;         // the uploaded boxes are the nested min/max boxes the proof step needs
@@ -1094,10 +1100,19 @@ int paths_frames_cap(const RtContext *ctx) {
     return g;
 }
 
-int paths_occupancy(const RtContext *ctx) {
-    // Occupancy against spills: large scenes have more memory latency to hide (7 waves per
-    // SIMD, 16 spilled values), small ones spend their time in the finish block (6 waves, 7 spilled).
-    return ctx->pathsOcc ? std::min(std::max(ctx->pathsOcc, 5), 7) : (ctx->nTris >= 65536 ? 7 : 6);
+// Waves per SIMD the path kernel runs at for a scene of n triangles.  More waves hide more of the
+// wait for the slowest lane of each node or triangle fetch; the registers this leaves (64 at 8
+// waves, 72 at 7) cost spills in the finish block only.  Measured 8 against 7 waves (6 on the demo
+// scene): 1.31M triangles +1 %, 262k at 4K +1.5 %, the 32-triangle demo scene +2 %, 10.5M -1.3 %.
+int paths_occupancy_for(const RtContext *ctx, int64_t n) {
+    return ctx->pathsOcc ? std::min(std::max(ctx->pathsOcc, 5), 8) : (n >= ((int64_t)4 << 20) ? 7 : 8);
+}
+int paths_occupancy(const RtContext *ctx) { return paths_occupancy_for(ctx, ctx->nTris); }
+// Deferred-node slots per lane in LDS: with the 6 queue entries, a block of 256 lanes may take 1/8
+// resp. 1/7 of a CU's 160 KB (allocated in units of 1280 bytes) for 8 resp. 7 waves per SIMD.
+int index_lds_entries_for(const RtContext *ctx, int64_t n) {
+    if (ctx->accelLdsEntries > 0) return ctx->accelLdsEntries;
+    return paths_occupancy_for(ctx, n) >= 8 ? 14 : 16;
 }
 
 size_t stack_bytes(const RtContext *ctx) { return (size_t)ctx->scene.stackEntries * BLOCK * sizeof(uint32_t); }
@@ -1364,7 +1379,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
         S.originLimit = 4.0f * (S.cullEps * 1024.0f);
         // deferred-node slots: the first ones in LDS, the rest (rarely reached) in global memory
         const int need = indexStackNeed;
-        S.aldsEntries = std::min(need, ctx->accelLdsEntries);
+        S.aldsEntries = std::min(need, index_lds_entries_for(ctx, n));
         S.aovfStride = (uint32_t)ctx->numCU * 8u * BLOCK;
         // overflow column per thread: the deeper deferred nodes, or the whole stack of an exact re-trace
         S.aovfRetrace = (uint32_t)std::max(need - S.aldsEntries, 0);
@@ -1679,6 +1694,7 @@ int render_now(RtContext *ctx, int first_loopnum, int count, const float *rand_o
                 if (cnt) LAUNCH_PATHS(true, true, true, 5);
                 else if (occ == 5) LAUNCH_PATHS(true, true, false, 5);
                 else if (occ == 7) LAUNCH_PATHS(true, true, false, 7);
+                else if (occ == 8) LAUNCH_PATHS(true, true, false, 8);
                 else LAUNCH_PATHS(true, true, false, 6);
             }
             else if (cull) { if (cnt) LAUNCH_PATHS(false, true, true, 5); else LAUNCH_PATHS(false, true, false, 5); }

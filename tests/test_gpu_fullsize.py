@@ -73,9 +73,10 @@ def test_benchmark_workload_at_full_size(name, index):
     r.set_options(max_bounces=bounces, index_build=build)   # defaults: persistent pipeline, search index
     info = r.scene_info()
     assert info["index_built_on_device"] == int(index == "gpu" or (index == "auto" and tris.shape[0] >= rt.INDEX_AUTO_GPU_TRIANGLES))
-    # (v) what the benchmark runs: the 7-wave variant, an index deeper than its LDS stack
+    # (v) what the benchmark runs: the 8-wave variant (7 from 4M triangles on), an index deeper than its LDS stack
     assert info["triangles"] == tris.shape[0] >= 65536
-    assert info["index_enabled"] == 1 and info["paths_waves_per_simd"] == 7
+    assert info["index_enabled"] == 1 and info["paths_waves_per_simd"] == (7 if tris.shape[0] >= (4 << 20) else 8)
+    assert info["index_stack_lds"] == (16 if tris.shape[0] >= (4 << 20) else 14)
     assert info["index_stack_need"] > info["index_stack_lds"] > 0
     assert info["tree_height"] >= 18
 

@@ -484,6 +484,33 @@ def test_synthetic_mesh_parity_and_work_counters():
             assert s["node_tests"] == st["nodeTests"] and s["tri_tests"] == st["triTests"] and s["tri_hits"] == st["triHits"]
 
 
+@pytest.mark.parametrize("occ,entries", [(5, None), (6, None), (7, None), (8, None), (8, 3), (7, 1)])
+def test_every_occupancy_variant_of_the_path_kernel(occ, entries, monkeypatch):
+    """The path kernel is compiled for 5, 6, 7 and 8 waves per SIMD (different register budgets,
+    different spills) and picks one by scene size; RT_AMD_PATHS_OCC forces one.  Each must render
+    the oracle's image, also with an LDS stack so short that deferred nodes overflow to memory."""
+    W, H = 160, 90
+    sc = rt.Scene()
+    sc.push_synthetic(0, 4, 1, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 3)
+    want, _ = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro)
+    monkeypatch.setenv("RT_AMD_PATHS_OCC", str(occ))
+    if entries is not None:
+        monkeypatch.setenv("RT_AMD_ACCEL_LDS_ENTRIES", str(entries))
+    r = rt.Renderer(W, H)
+    r.upload(tris, nodes)
+    r.set_spheres(sc.spheres())
+    r.set_camera(cam)
+    info = r.scene_info()
+    assert info["paths_waves_per_simd"] == occ
+    assert info["index_stack_lds"] == (entries if entries is not None else min(info["index_stack_need"], 14 if occ == 8 else 16))
+    r.render(1, ro)
+    assert _same_image(r.read_mean(), want)
+    assert r.stats()["retraced"] <= 0.001 * r.stats()["rays"] + 5
+
+
 @pytest.mark.parametrize("kind,level,copies,bounces", [(1, 6, 1, 4), (0, 3, 8, 8)])
 def test_benchmark_scene_families_at_low_subdivision(kind, level, copies, bounces):
     """The other two benchmark scenes in small: the column hall (diffuse / mirror / glass columns,
