@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--host-index", action="store_true", help="build the search index on the host (default: auto)")
     ap.add_argument("--checksum", action="store_true", help="print a hash of the resulting mean image")
     ap.add_argument("--per-call", type=int, default=0, help="frames per rt_render_frames call (default: all at once)")
+    ap.add_argument("--sync-each-call", action="store_true", help="rt_synchronize after every call (a loop that looks at each frame)")
     a = ap.parse_args()
     sc = rt.Scene()
     if a.demo:
@@ -60,6 +61,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(0, a.frames, step):
         r.render(a.warmup + 1 + k, ro[a.warmup + k:a.warmup + min(k + step, a.frames)])
+        if a.sync_each_call:
+            r.synchronize()
     r.synchronize()
     dt = time.perf_counter() - t0
     st = r.stats()
