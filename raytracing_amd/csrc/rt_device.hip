@@ -129,9 +129,11 @@ __device__ __forceinline__ void store_path(const PathSoA &Q, uint32_t slot, cons
 // generate: one wave per 8x8 pixel tile; writes the camera rays of one frame into queue 0
 // (a tile stays together in one chunk, so a wave of the extend stage starts on a coherent
 // tile) and clears the frame's sample image.
+// frameSlot / bitsX / bitsY: the frame's place in a batch of frames that share the queues, and the
+// layout of the pixel word px | py << bitsX | frameSlot << (bitsX + bitsY); cur is the frame's own image.
 __global__ __launch_bounds__(BLOCK) void k_generate(const FrameD F, const float randOrigin, const PathSoA Q,
                                                     const uint32_t cap, uint32_t *__restrict__ qcount,
-                                                    float *__restrict__ cur) {
+                                                    float *__restrict__ cur, const uint32_t frameSlot, const int bitsX, const int bitsY) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     uint32_t px, py;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(const FrameD F, const float 
     }
     const uint32_t shard = (uint32_t)tile % NSHARD;
     const uint32_t slot = shard * cap + wave_push(qcount + shard * CTL_STRIDE, valid);
-    if (valid) store_path(Q, slot, p, (py << 16) | px);
+    if (valid) store_path(Q, slot, p, px | (py << bitsX) | (frameSlot << (bitsX + bitsY)));
 }
 
 // extend: persistent waves pull rays from the sharded queue until every shard is empty.  A lane
@@ -312,11 +314,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
                                                  const uint32_t *__restrict__ sobV, const PathSoA Qin, const uint32_t cap, const uint32_t *__restrict__ qcountIn,
                                                  const float *__restrict__ hitT, const uint32_t *__restrict__ hitTri,
                                                  const PathSoA Qout, uint32_t *__restrict__ qcountOut,
-                                                 float *__restrict__ cur) {
+                                                 float *__restrict__ cur, const int bitsX, const int bitsY,
+                                                 const float *__restrict__ sobTable, const uint32_t frameFloats) {
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t total = NSHARD * cap;        // cap is a multiple of 64: a wave never straddles shards
-    float su, sv;
-    sobol_pair(sobV, loopNum, (uint32_t)bounce, su, sv);
+    // one frame: its Sobol pair for this bounce; a batch of frames: sobTable[(frame slot * maxBounces + bounce) * 2]
+    float su = 0.0f, sv = 0.0f;
+    if (!sobTable) sobol_pair(sobV, loopNum, (uint32_t)bounce, su, sv);
+    const uint32_t maskX = (1u << bitsX) - 1u, maskY = (1u << bitsY) - 1u;
     for (uint32_t v0 = blockIdx.x * BLOCK; v0 < total; v0 += stride) {
         const uint32_t v = v0 + threadIdx.x;
         const uint32_t shardIn = v / cap, idx = v - shardIn * cap;
@@ -330,11 +335,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(const SceneD S, const FrameD F,
             p.thr = rtm::mk(Qin.tr[slot], Qin.tg[slot], Qin.tb[slot]);
             p.seed = Qin.seed[slot];
             pix = Qin.pix[slot];
-            const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
+            const uint32_t px = pix & maskX, py = (pix >> bitsX) & maskY, fslot = pix >> (bitsX + bitsY);
+            if (sobTable) { const int si = ((int)fslot * F.maxBounces + bounce) * 2; su = sobTable[si]; sv = sobTable[si + 1]; }
             vec3 sample;
             goOn = shade_hit<EXT>(F, S, p, hitT[slot], hitTri[slot], bounce, su, sv, px, py, sample);
             if (!goOn && (sample.x != 0.0f || sample.y != 0.0f || sample.z != 0.0f)) {
-                const size_t o3 = ((size_t)py * (size_t)F.width + px) * 3;
+                const size_t o3 = (size_t)fslot * frameFloats + ((size_t)py * (size_t)F.width + px) * 3;
                 cur[o3] = sample.x; cur[o3 + 1] = sample.y; cur[o3 + 2] = sample.z;
             }
         }
@@ -363,6 +369,13 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float *__restrict__ 
     const float m = rtm::madd(wa, c, wb * mean[i]);
     mean[i] = history8 ? store_unorm8(m) : m;
     sum[i] += c;
+}
+
+// The rays of a batch of the wavefront pipeline: the fill counts of all its queues.
+__global__ void k_count_queue_rays(const uint32_t *__restrict__ qcounts, const int nqueues, WorkCounters *__restrict__ wc) {
+    unsigned long long rays = 0;
+    for (int q = 0; q < nqueues * NSHARD; q++) rays += qcounts[q * CTL_STRIDE];
+    atomicAdd(&wc->rays, rays);
 }
 
 // Every fp32 bit pattern through recip_exact / sqrt_exact / rsqrt_exact against the compiler's IEEE
@@ -815,6 +828,10 @@ struct RtContext {
     float *dHitT = nullptr; uint32_t *dHitTri = nullptr;
     uint32_t *dQueueCtl = nullptr;  // fill counts and dequeue heads of the sharded queues
     uint32_t queueCap = 0;          // slots per shard (multiple of 64)
+    // experiment (RT_AMD_WAVEFRONT_FRAMES): queues, hit records and sample images for wfFrames frames at a time
+    int wfFrames = 1, wfAllocFrames = 0;
+    float *wfPathMem = nullptr, *wfHitT = nullptr, *wfCur = nullptr, *wfSobTable = nullptr; uint32_t *wfHitTri = nullptr;
+    PathSoA wfQ[2];
     int extendBlocksPerCU = 7;
     float *dRandOrigin = nullptr; int randCap = 0;
     // persistent-path pipeline: one sample image per frame of a batch, and the item counter
@@ -1193,6 +1210,7 @@ int rt_create(RtContext **out, int width, int height, int device) {
         if (v >= 1 && v <= 8) ctx->extendBlocksPerCU = v;
     }
     if (const char *env = getenv("RT_AMD_PATHS_OCC")) ctx->pathsOcc = atoi(env);
+    if (const char *env = getenv("RT_AMD_WAVEFRONT_FRAMES")) { const int v = atoi(env); if (v >= 1 && v <= PATHS_MAX_FRAMES) ctx->wfFrames = v; }
     if (const char *env = getenv("RT_AMD_SLOTS")) { const int v = atoi(env); if (v >= 2 && v <= NSLOT) ctx->nSlots = v; }
     if (const char *env = getenv("RT_AMD_GRID_DIV")) { const int v = atoi(env); if (v >= 1 && v <= 8) ctx->gridDiv = v; }
     if (const char *env = getenv("RT_AMD_PATHS_LEAF_BATCH")) { const int v = atoi(env); if (v >= 1 && v <= 64) ctx->pathsLeafBatch = v; }
@@ -1228,6 +1246,7 @@ void rt_destroy(RtContext *ctx) {
     for (auto &p : ctx->dAOvf) hipFree(p);
     hipFree(ctx->dSumOwned); hipFree(ctx->dMean); hipFree(ctx->dCur);
     hipFree(ctx->dPathMem); hipFree(ctx->dHitT); hipFree(ctx->dHitTri);
+    hipFree(ctx->wfPathMem); hipFree(ctx->wfHitT); hipFree(ctx->wfHitTri); hipFree(ctx->wfCur); hipFree(ctx->wfSobTable);
     hipFree(ctx->dQueueCtl); hipFree(ctx->dCounters); hipFree(ctx->dRandOrigin); hipFree(ctx->dSobolV);
     for (auto &sl : ctx->slot) {
         if (sl.stream) { hipStreamSynchronize(sl.stream); hipStreamDestroy(sl.stream); }
@@ -1724,44 +1743,91 @@ int render_now(RtContext *ctx, int first_loopnum, int count, const float *rand_o
         return RT_OK;
     }
 
-    // wavefront pipeline, one frame at a time
+    // wavefront pipeline: one frame at a time, or (experiment, RT_AMD_WAVEFRONT_FRAMES=n) n frames share the
+    // queues, so that every launch ends with the longest ray of n frames instead of one
+    int wbitsX = 1, wbitsY = 1;
+    while ((1 << wbitsX) < ctx->width) wbitsX++;
+    while ((1 << wbitsY) < ctx->height) wbitsY++;
+    const int wf = std::max(1, std::min(ctx->wfFrames, paths_frames_cap(ctx)));
     const int extendBlocks = ctx->numCU * ctx->extendBlocksPerCU;   // persistent waves
-    const uint32_t cap = ctx->queueCap;
-    const int shadeBlocks = (int)std::min<size_t>(((size_t)cap * NSHARD + BLOCK - 1) / BLOCK, (size_t)ctx->numCU * 32);
     const size_t nfloats = (size_t)ctx->width * ctx->height * 3;
+    uint32_t cap = ctx->queueCap;
+    const PathSoA *wq = ctx->q;
+    float *hitT = ctx->dHitT; uint32_t *hitTri = ctx->dHitTri; float *curImg = ctx->dCur; float *sobTable = nullptr;
+    if (wf > 1) {
+        if ((uint64_t)ctx->queueCap * (uint64_t)wf * NSHARD >= ((uint64_t)1 << 31)) return fail(ctx, RT_E_INVALID, "rt_render_frames: RT_AMD_WAVEFRONT_FRAMES too large for this image size");
+        if (ctx->wfAllocFrames != wf) {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            hipFree(ctx->wfPathMem); hipFree(ctx->wfHitT); hipFree(ctx->wfHitTri); hipFree(ctx->wfCur); hipFree(ctx->wfSobTable);
+            ctx->wfPathMem = nullptr; ctx->wfHitT = nullptr; ctx->wfHitTri = nullptr; ctx->wfCur = nullptr; ctx->wfSobTable = nullptr; ctx->wfAllocFrames = 0;
+            const size_t P = (size_t)ctx->queueCap * wf * NSHARD;
+            HIP_TRY(ctx, hipMalloc(&ctx->wfPathMem, 2 * 11 * P * sizeof(float)));
+            HIP_TRY(ctx, hipMalloc(&ctx->wfHitT, P * sizeof(float)));
+            HIP_TRY(ctx, hipMalloc(&ctx->wfHitTri, P * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc(&ctx->wfCur, (size_t)wf * nfloats * sizeof(float)));
+            HIP_TRY(ctx, hipMalloc(&ctx->wfSobTable, (size_t)PATHS_MAX_FRAMES * RT_MAX_BOUNCES * 2 * sizeof(float)));
+            for (int b = 0; b < 2; b++) {
+                float *base = ctx->wfPathMem + (size_t)b * 11 * P;
+                PathSoA &q = ctx->wfQ[b];
+                q.ox = base; q.oy = base + P; q.oz = base + 2 * P;
+                q.dx = base + 3 * P; q.dy = base + 4 * P; q.dz = base + 5 * P;
+                q.tr = base + 6 * P; q.tg = base + 7 * P; q.tb = base + 8 * P;
+                q.seed = (uint32_t *)(base + 9 * P); q.pix = (uint32_t *)(base + 10 * P);
+            }
+            ctx->wfAllocFrames = wf;
+        }
+        cap = ctx->queueCap * (uint32_t)wf;
+        wq = ctx->wfQ; hitT = ctx->wfHitT; hitTri = ctx->wfHitTri; curImg = ctx->wfCur; sobTable = ctx->wfSobTable;
+    }
+    const int shadeBlocks = (int)std::min<size_t>(((size_t)cap * NSHARD + BLOCK - 1) / BLOCK, (size_t)ctx->numCU * 32);
     const int accBlocks = (int)((nfloats + BLOCK - 1) / BLOCK);
     uint32_t *counts = ctx->dQueueCtl, *heads = ctx->dQueueCtl + QCTL_COUNTS;
     const int qstride = NSHARD * CTL_STRIDE;
     const bool useAccel = ctx->opt.accel != 0 && S.anodes != nullptr;
     const size_t ldsFast = fast_stack_bytes(ctx);
     ctx->inputDirty = true;             // accumulators and slot 0's overflow columns are used on the context's stream
-    for (int f = 0; f < count; f++) {
-        const int loopNum = first_loopnum + f;
+    for (int f0 = 0; f0 < count; f0 += wf) {
+        const int nf = std::min(wf, count - f0);
+        const int loopNum = first_loopnum + f0;
         HIP_TRY(ctx, hipMemsetAsync(ctx->dQueueCtl, 0, QCTL_WORDS * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_generate, dim3(tileBlocks), dim3(BLOCK), 0, st, F, rand_origin[f], ctx->q[0], cap, counts, ctx->dCur);
+        if (wf > 1) {
+            BatchD B;
+            B.firstLoopNum = loopNum; B.nframes = nf; B.bitsX = wbitsX; B.bitsY = wbitsY;
+            for (int k = 0; k < PATHS_MAX_FRAMES; k++) B.randOrigin[k] = 0.0f;
+            const int sobWords = nf * F.maxBounces * 2;
+            hipLaunchKernelGGL(k_sobol_table, dim3((sobWords + 255) / 256), dim3(256), 0, st, B, F.maxBounces, ctx->dSobolV, sobTable);
+        }
+        for (int k = 0; k < nf; k++)
+            hipLaunchKernelGGL(k_generate, dim3(tileBlocks), dim3(BLOCK), 0, st, F, rand_origin[f0 + k], wq[0], cap, counts, curImg + (size_t)k * nfloats,
+                               (uint32_t)k, wbitsX, wbitsY);
         for (int b = 0; b < F.maxBounces; b++) {
-            const PathSoA &qin = ctx->q[b & 1], &qout = ctx->q[(b + 1) & 1];
+            const PathSoA &qin = wq[b & 1], &qout = wq[(b + 1) & 1];
             hipEvent_t e0 = take_event(ctx), e1 = take_event(ctx);
             if (!e0 || !e1) { give_back_events(ctx, e0, e1); return fail(ctx, RT_E_HIP, "rt_render_frames: hipEventCreate failed"); }
             ctx->pendingEvents.emplace_back(e0, e1);
             HIP_TRY(ctx, hipEventRecord(e0, st));
             if (useAccel) {
-                if (cnt) hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
-                else hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters);
+                if (cnt) hipLaunchKernelGGL((k_extend_fast<true>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, hitT, hitTri, ctx->dCounters);
+                else hipLaunchKernelGGL((k_extend_fast<false>), dim3(extendBlocks), dim3(BLOCK), ldsFast, st, S, qin, cap, counts + b * qstride, heads + b * qstride, hitT, hitTri, ctx->dCounters);
             } else {
-#define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, ctx->dHitT, ctx->dHitTri, ctx->dCounters)
+#define LAUNCH_EXT(C, N) hipLaunchKernelGGL((k_extend<C, N>), dim3(extendBlocks), dim3(BLOCK), lds, st, S, qin, cap, counts + b * qstride, heads + b * qstride, hitT, hitTri, ctx->dCounters)
                 if (cull) { if (cnt) LAUNCH_EXT(true, true); else LAUNCH_EXT(true, false); }
                 else { if (cnt) LAUNCH_EXT(false, true); else LAUNCH_EXT(false, false); }
 #undef LAUNCH_EXT
             }
             HIP_TRY(ctx, hipEventRecord(e1, st));
             if (ext) hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
-                                         ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
+                                         hitT, hitTri, qout, counts + (b + 1) * qstride, curImg, wbitsX, wbitsY, (const float *)sobTable, (uint32_t)nfloats);
             else hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocks), dim3(BLOCK), 0, st, S, F, b, (uint32_t)loopNum, ctx->dSobolV, qin, cap, counts + b * qstride,
-                                    ctx->dHitT, ctx->dHitTri, qout, counts + (b + 1) * qstride, ctx->dCur);
+                                    hitT, hitTri, qout, counts + (b + 1) * qstride, curImg, wbitsX, wbitsY, (const float *)sobTable, (uint32_t)nfloats);
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, ctx->dCur, ctx->dSum, ctx->dMean, nfloats, loopNum,
-                           counts, F.maxBounces, ctx->opt.history8, ctx->dCounters);
+        if (wf > 1) {
+            hipLaunchKernelGGL(k_count_queue_rays, dim3(1), dim3(1), 0, st, counts, F.maxBounces, ctx->dCounters);
+            hipLaunchKernelGGL(k_accumulate_batch, dim3(accBlocks), dim3(BLOCK), 0, st, curImg, ctx->dSum, ctx->dMean, nfloats, loopNum, nf, ctx->opt.history8);
+        } else {
+            hipLaunchKernelGGL(k_accumulate, dim3(accBlocks), dim3(BLOCK), 0, st, curImg, ctx->dSum, ctx->dMean, nfloats, loopNum,
+                               counts, F.maxBounces, ctx->opt.history8, ctx->dCounters);
+        }
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->frames += (uint64_t)count;

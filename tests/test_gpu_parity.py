@@ -511,6 +511,32 @@ def test_every_occupancy_variant_of_the_path_kernel(occ, entries, monkeypatch):
     assert r.stats()["retraced"] <= 0.001 * r.stats()["rays"] + 5
 
 
+@pytest.mark.parametrize("frames_per_pass", [3, 8])
+def test_wavefront_pipeline_with_frame_batches(frames_per_pass, monkeypatch):
+    """RT_AMD_WAVEFRONT_FRAMES lets the per-bounce pipeline push several frames through its queues
+    at a time (an image size that is no multiple of the tile, a frame count that is no multiple of
+    the batch, spheres, mixed materials): same image, same ray count as the oracle."""
+    W, H = 130, 70
+    sc = rt.Scene()
+    sc.push_synthetic(1, 6, 1, 12345)
+    tris, nodes = rt.bvh_build(sc.triangles())
+    cam = rt.camera_default(W, H)
+    ro = rt.rand_origins(20221003, 7)
+    want, st = _oracle_for(tris, nodes, W, H, sc.spheres()).render(cam, 1, ro, want_stats=True)
+    monkeypatch.setenv("RT_AMD_WAVEFRONT_FRAMES", str(frames_per_pass))
+    for accel in (True, False):
+        r = rt.Renderer(W, H)
+        r.upload(tris, nodes)
+        r.set_spheres(sc.spheres())
+        r.set_camera(cam)
+        r.set_options(pipeline=rt.PIPELINE_WAVEFRONT, accel=accel)
+        r.render(1, ro[:5])
+        r.render(6, ro[5:])
+        assert _same_image(r.read_mean(), want), accel
+        assert r.stats()["rays"] == st["rays"] and r.stats()["frames"] == 7
+        r.close()
+
+
 @pytest.mark.parametrize("kind,level,copies,bounces", [(1, 6, 1, 4), (0, 3, 8, 8)])
 def test_benchmark_scene_families_at_low_subdivision(kind, level, copies, bounces):
     """The other two benchmark scenes in small: the column hall (diffuse / mirror / glass columns,

@@ -27,6 +27,12 @@ WORK = {
     "dragon1m_f2": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "8", "--per-call", "2"],
     "demo_f1": ["--demo", "--frames", "64", "--warmup", "8", "--per-call", "1"],
     "stress10m_f1": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "8", "--per-call", "1"],
+    "small_wf": ["--kind", "0", "--level", "4", "--width", "160", "--height", "90", "--frames", "24", "--warmup", "8", "--pipeline", "0"],
+    "small": ["--kind", "0", "--level", "4", "--width", "160", "--height", "90", "--frames", "24", "--warmup", "8"],
+    "dragon1m_wf": ["--kind", "0", "--level", "8", "--copies", "1", "--frames", "64", "--warmup", "64", "--pipeline", "0"],
+    "stress10m_wf": ["--kind", "0", "--level", "8", "--copies", "8", "--bounces", "8", "--frames", "64", "--warmup", "64", "--pipeline", "0"],
+    "sponza_wf": ["--kind", "1", "--level", "64", "--width", "3840", "--height", "2160", "--frames", "16", "--warmup", "16", "--pipeline", "0"],
+    "demo_wf": ["--demo", "--frames", "64", "--warmup", "64", "--pipeline", "0"],
     "sponza_f1": ["--kind", "1", "--level", "64", "--width", "3840", "--height", "2160", "--frames", "24", "--warmup", "4", "--per-call", "1"],
 }
 
