@@ -468,6 +468,13 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
     const unsigned long long tlStart = wall_clock64();
     unsigned long long tlIter = 0, tlExhausted = 0;
     uint32_t tlRetrace = 0;
+    // shader-clock cycles of the wave inside the finish, node and triangle blocks (their waits for memory included)
+    unsigned long long tlGo = 0, tlNode = 0, tlTest = 0, tlNodeWait = 0;
+#define RT_TL_BEGIN() const unsigned long long tlT0 = (__builtin_amdgcn_sched_barrier(0), __builtin_amdgcn_s_memtime())
+#define RT_TL_END(acc) do { __builtin_amdgcn_sched_barrier(0); acc += __builtin_amdgcn_s_memtime() - tlT0; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RT_TL_BEGIN() do {} while (0)
+#define RT_TL_END(acc) do {} while (0)
 #endif
     typename std::conditional<FAST, FastTrav<COUNT>, Trav<CULL, COUNT>>::type tv;
     tv.cur = REF_NONE;
@@ -525,6 +532,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             go = go || (nFin >= (need > 0u ? need : 1u));
         }
         if (go) {
+            RT_TL_BEGIN();
 #ifdef RT_EXP_PROFILE
             xGo += 1ull + ((unsigned long long)nFin << 32);
 #endif
@@ -658,6 +666,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 haveMask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
             }
+            RT_TL_END(tlGo);
             if (haveMask == 0ull) {
                 if (exhausted && cNext >= cEnd) break;
                 continue;
@@ -674,7 +683,23 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             { const unsigned long long mt = ballot64(step && tv.cur < (uint32_t)(RT_EXP_TOPK)); xTest += (mt ? 1ull : 0ull) + ((unsigned long long)__popcll(mt) << 32); }
 #endif
 #endif
+#ifdef RT_EXP_TIMELINE
+            {
+                // the node block in two parts: until the records have arrived, and the step proper
+                RT_TL_BEGIN();
+                float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+                if (step) { const float4 *rec = RT_REC(S.anodes, tv.cur, 64u); q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long tlT1 = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+                tlNodeWait += tlT1 - tlT0;
+                if (step) tv.node_process(S, q0, q1, q2, q3, stack, PATHS_BLOCK, ovf, cNode);
+                RT_TL_END(tlNode);
+            }
+#else
             if (step) tv.node_step(S, stack, PATHS_BLOCK, ovf, cNode);
+#endif
             // wants_test() and can_step() of every lane, from three compares and scalar logic
             const unsigned long long mNone = ballot64(tv.cur == REF_NONE);
             const unsigned long long mFull = ballot64(tv.npend > FastTrav<COUNT>::PEND_MAX - 4);
@@ -685,7 +710,9 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
 #if defined(RT_EXP_PROFILE) && !defined(RT_EXP_TOPK)
                 xTest += 1ull + ((unsigned long long)__popcll(ballot64(tv.npend > 0)) << 32);
 #endif
+                RT_TL_BEGIN();
                 if (tv.npend > 0) tv.test_step(S, stack, PATHS_BLOCK, cTri);
+                RT_TL_END(tlTest);
             }
         } else {
             if (have) {
@@ -699,8 +726,9 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
         uint32_t r = cRays, rt2 = tlRetrace;
         for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt2 += __shfl_down(rt2, off); }
         if (lane == 0) {
-            unsigned long long *o = S.timeline + (size_t)(blockIdx.x * (PATHS_BLOCK / 64) + (threadIdx.x >> 6)) * 5;
+            unsigned long long *o = S.timeline + (size_t)(blockIdx.x * (PATHS_BLOCK / 64) + (threadIdx.x >> 6)) * 10;
             o[0] = tlStart; o[1] = wall_clock64(); o[2] = r | ((unsigned long long)rt2 << 32); o[3] = tlIter; o[4] = tlExhausted;
+            o[5] = tlGo; o[6] = tlNode; o[7] = tlTest; o[8] = tlNodeWait; o[9] = 0;
         }
     }
 #endif
@@ -1410,7 +1438,7 @@ int rt_scene_upload(RtContext *ctx, const RtTriangle *tris, int64_t n, const RtL
 #ifdef RT_EXP_TIMELINE
     {
         static unsigned long long *tl = nullptr;
-        if (!tl) HIP_TRY(ctx, hipMalloc(&tl, (size_t)ctx->numCU * 8 * 4 * 5 * sizeof(unsigned long long)));
+        if (!tl) HIP_TRY(ctx, hipMalloc(&tl, (size_t)ctx->numCU * 8 * 4 * 10 * sizeof(unsigned long long)));
         S.timeline = tl;
     }
 #endif
@@ -2127,7 +2155,7 @@ int rt_selftest_arith(RtContext *ctx, const float *a, const float *b, int64_t n,
 int rt_debug_timeline(RtContext *ctx, unsigned long long *out, int64_t waves) {
     if (!ctx || !out || !ctx->scene.timeline) return RT_E_INVALID;
     hipDeviceSynchronize();
-    return hipMemcpy(out, ctx->scene.timeline, (size_t)waves * 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? RT_OK : RT_E_HIP;
+    return hipMemcpy(out, ctx->scene.timeline, (size_t)waves * 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? RT_OK : RT_E_HIP;
 }
 #endif
 

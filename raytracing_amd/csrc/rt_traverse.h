@@ -295,6 +295,11 @@ struct FastTrav {
     __device__ __forceinline__ void node_step(const SceneD &S, uint32_t *col, const int stride, uint32_t *ovf, uint32_t &nNode) {
         const float4 *rec = RT_REC(S.anodes, cur, 64u);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        node_process(S, q0, q1, q2, q3, col, stride, ovf, nNode);
+    }
+    // the step proper, for the node whose record is q0..q3
+    __device__ __forceinline__ void node_process(const SceneD &S, const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                                 uint32_t *col, const int stride, uint32_t *ovf, uint32_t &nNode) {
         const float Ax = q0.w * inv.x, Bx = (q0.x - o.x) * inv.x;
         const float Ay = q3.z * inv.y, By = (q0.y - o.y) * inv.y;
         const float Az = q3.w * inv.z, Bz = (q0.z - o.z) * inv.z;

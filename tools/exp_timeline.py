@@ -17,8 +17,8 @@ ro = rt.rand_origins(20221003, 8 + frames)
 r.render(1, ro[:8]); r.synchronize(); r.reset()
 r.render(9, ro[8:]); r.synchronize()
 ms, n = r.kernel_time()
-waves = 256 * int(os.environ.get("WAVES_PER_SIMD", "7")) * 4
-buf = np.zeros((waves, 5), dtype=np.uint64)
+waves = 256 * int(os.environ.get("WAVES_PER_SIMD", "8")) * 4
+buf = np.zeros((waves, 10), dtype=np.uint64)
 rt.lib.rt_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 assert rt.lib.rt_debug_timeline(r._h, buf.ctypes.data_as(C.c_void_p), waves) == 0
 retr = (buf[:, 2] >> np.uint64(32)).astype(np.int64)          # rays of the wave traced again in reference order
@@ -47,3 +47,11 @@ endt = (t1 - base) * tick
 order = np.argsort(endt)[::-1][:12]
 print("last waves to end (us, rays traced again in the wave):", [(int(endt[i]), int(retr[i])) for i in order])
 print(f"waves with a re-trace: {int((retr > 0).sum())}; their end: median {np.median(endt[retr > 0]) if (retr > 0).any() else 0:.0f} us; others: p99 {np.percentile(endt[retr == 0], 99):.0f}, max {endt[retr == 0].max():.0f} us")
+# shader-clock cycles inside the three blocks (waits for memory included); the rest is the head of the loop
+life = (t1 - t0) * tick                      # us
+go, node, test, nwait = (buf[:, k].astype(np.float64) for k in (5, 6, 7, 8))
+tot = go + node + test
+print(f"cycles in blocks per us of wave life (median): {np.median(tot / np.maximum(life, 1e-9)):.0f} (the shader clock in MHz if the head of the loop were free)")
+print(f"share of the block cycles: finish {go.sum() / tot.sum():.3f}, node {node.sum() / tot.sum():.3f} (of it waiting for the records {nwait.sum() / tot.sum():.3f}), triangle {test.sum() / tot.sum():.3f}")
+it = buf[:, 3].astype(np.float64)
+print(f"cycles per iteration: node block {node.sum() / it.sum():.0f} (wait {nwait.sum() / it.sum():.0f}); triangle block {test.sum() / it.sum():.0f}; finish block {go.sum() / it.sum():.0f}")
