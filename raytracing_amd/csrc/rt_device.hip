@@ -683,7 +683,15 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             { const unsigned long long mt = ballot64(step && tv.cur < (uint32_t)(RT_EXP_TOPK)); xTest += (mt ? 1ull : 0ull) + ((unsigned long long)__popcll(mt) << 32); }
 #endif
 #endif
-#ifdef RT_EXP_TIMELINE
+#if defined(RT_EXP_PROFILE) && defined(RT_EXP_EMPTY)
+            {   // node steps in which no child was hit (reported in place of the test blocks): the node had
+                // been deferred and lies beyond the closest hit by now, or the ray passes between its children
+                const int npBefore = tv.npend, spBefore = tv.sp;
+                if (step) tv.node_step(S, stack, PATHS_BLOCK, ovf, cNode);
+                const unsigned long long me = ballot64(step && tv.npend == npBefore && (tv.sp < spBefore || (spBefore == 0 && tv.cur == REF_NONE)));
+                xTest += (me ? 1ull : 0ull) + ((unsigned long long)__popcll(me) << 32);
+            }
+#elif defined(RT_EXP_TIMELINE)
             {
                 // the node block in two parts: until the records have arrived, and the step proper
                 RT_TL_BEGIN();
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
             const unsigned long long waiting = mPend & (mNone | mFull);
             const unsigned long long stepping = ~(mNone | mFull);
             if (waiting != 0ull && ((int)__popcll(waiting) >= S.leafBatch || stepping == 0ull)) {
-#if defined(RT_EXP_PROFILE) && !defined(RT_EXP_TOPK)
+#if defined(RT_EXP_PROFILE) && !defined(RT_EXP_TOPK) && !defined(RT_EXP_EMPTY)
                 xTest += 1ull + ((unsigned long long)__popcll(ballot64(tv.npend > 0)) << 32);
 #endif
                 RT_TL_BEGIN();

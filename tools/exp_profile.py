@@ -6,7 +6,11 @@ finish block executions and the lanes active in each).  Needs a library built wi
         -o /tmp/librt_profile.so raytracing_amd/csrc/rt_{device.hip,bvh.cpp,host.cpp,scene.cpp,accel.cpp} -lpthread
   RT_AMD_LIBRARY=/tmp/librt_profile.so python3 tools/exp_profile.py
 
-(the counters reuse the work-counter fields, so that build reports no box/triangle statistics)."""
+(the counters reuse the work-counter fields, so that build reports no box/triangle statistics).
+With -DRT_EXP_TOPK=K the "test blocks" line counts node steps at the first K nodes of the index instead,
+with -DRT_EXP_EMPTY node steps in which no child was hit (measured: 1.39 of 9.45 per ray on the
+1.31M-triangle scene, 1.63 of 10.75 on 10.5M: deferred nodes that lie beyond the closest hit by the time
+they are taken up, and rays that pass between the children of a node)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracing_amd as rt
