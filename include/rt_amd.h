@@ -103,7 +103,7 @@ typedef struct RtSceneInfo {
     int32_t index_enabled;          /* 0: the tree's boxes are not the exact nested min/max boxes the
                                        proof step relies on (or the index was switched off), every
                                        ray is traced in the reference's order */
-    int32_t paths_waves_per_simd;   /* variant of the persistent path kernel used for this scene: 5, 6 or 7 */
+    int32_t paths_waves_per_simd;   /* variant of the persistent path kernel used for this scene: 5..8 */
     int32_t frames_per_launch;      /* most frames one launch of the path kernel renders at this image size */
     int32_t index_built_on_device;  /* 1: the search index of this scene was built on the GPU (RtOptions.index_build) */
     int32_t index_build_fell_back;  /* 1: the device build of the index failed (no working memory, or a tree it
