@@ -689,7 +689,13 @@ __global__ __launch_bounds__(PATHS_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC
                 const int npBefore = tv.npend, spBefore = tv.sp;
                 if (step) tv.node_step(S, stack, PATHS_BLOCK, ovf, cNode);
                 const unsigned long long me = ballot64(step && tv.npend == npBefore && (tv.sp < spBefore || (spBefore == 0 && tv.cur == REF_NONE)));
+#if RT_EXP_EMPTY == 2
+                // ... and of those, the steps in which a child would have been hit but for the closest hit known by now
+                const unsigned long long mc = me & ballot64(tv.dbgWouldHit);
+                xTest += (mc ? 1ull : 0ull) + ((unsigned long long)__popcll(mc) << 32);
+#else
                 xTest += (me ? 1ull : 0ull) + ((unsigned long long)__popcll(me) << 32);
+#endif
             }
 #elif defined(RT_EXP_TIMELINE)
             {

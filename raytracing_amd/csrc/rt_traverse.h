@@ -223,6 +223,9 @@ struct FastTrav {
     // the tests.  The queue is the first PEND_MAX entries of the lane's LDS column, the
     // deferred nodes follow it.
     int npend;
+#ifdef RT_EXP_EMPTY
+    bool dbgWouldHit;           // experiment builds: the last node step had a child that only the known closest hit rules out
+#endif
 
     static constexpr int PEND_MAX = FAST_QUEUE_ENTRIES;     // a node step may queue up to 4 triangles
 
@@ -320,6 +323,13 @@ struct FastTrav {
                                     rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz))), hitCull));
         RT_CHILD(0, t0, hit0) RT_CHILD(8, t1, hit1) RT_CHILD(16, t2, hit2) RT_CHILD(24, t3, hit3)
 #undef RT_CHILD
+#ifdef RT_EXP_EMPTY
+        // experiment: would a child be hit if the closest hit so far were not known (hitCull = +inf)?
+#define RT_CHILD_NC(sh, k) !(k > fminf(rtm::madd((float)((frx >> sh) & 0xFFu), Ax, Bx), fminf(rtm::madd((float)((fry >> sh) & 0xFFu), Ay, By), \
+                                    rtm::madd((float)((frz >> sh) & 0xFFu), Az, Bz))))
+        dbgWouldHit = (RT_CHILD_NC(0, t0) && r0 != REF_NONE) || (RT_CHILD_NC(8, t1) && r1 != REF_NONE) || (RT_CHILD_NC(16, t2) && r2 != REF_NONE) || (RT_CHILD_NC(24, t3) && r3 != REF_NONE);
+#undef RT_CHILD_NC
+#endif
         if (COUNT) nNode += 4;
         // hit leaf children are queued for the triangle pass (stored with the leaf bit, removed when taken out)
         // Without branches: every child is written at the slot the next queued one would take, so a
