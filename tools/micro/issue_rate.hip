@@ -62,6 +62,11 @@ KERNEL(k_cvt_u32, asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_
 KERNEL(k_add_sdwa, asm volatile("v_add_u32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_add_u32_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_add_u32_sdwa %0, %0, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n v_add_u32_sdwa %1, %1, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "+v"(u), "+v"(w) : "v"(0x4B000000u), "v"(threadIdx.x));)
 KERNEL(k_cndmask_vcc2, asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, vcc\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");)
 KERNEL(k_lds, { extern __shared__ float lds[]; float *p = lds + threadIdx.x; asm volatile("ds_write_b32 %2, %0\n ds_read_b32 %1, %2\n s_waitcnt lgkmcnt(0)\n ds_write_b32 %2, %1 offset:1024\n ds_read_b32 %0, %2 offset:1024\n s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : "v"((unsigned int)(size_t)p) : "memory"); })
+KERNEL(k_cndmask_vcc_e64, asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_cndmask_b32_e64 %2, %2, %3, vcc\n v_cndmask_b32_e64 %3, %3, %0, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");)
+KERNEL(k_cndmask_vcc_indep, asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %4, %5, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %4, %5, vcc" : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(seed), "v"(1.0f) : "vcc");)
+KERNEL(k_cndmask_sgpr_indep, asm volatile("v_cndmask_b32_e64 %0, %4, %5, %6\n v_cndmask_b32_e64 %1, %4, %5, %6\n v_cndmask_b32_e64 %2, %4, %5, %6\n v_cndmask_b32_e64 %3, %4, %5, %6" : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(seed), "v"(1.0f), "s"(m));)
+KERNEL(k_fma_vcc_mix, asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %0, %3\n v_fma_f32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");)
+KERNEL(k_addc, asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %1, vcc, %1, %0, vcc\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %1, vcc, %1, %0, vcc" : "+v"(u), "+v"(w) : : "vcc");)
 KERNEL(k_div_chain, { a = a / b; b = b + 1.0f; c = c / d; d = d + 1.0f; })     // two IEEE divisions + two adds as the compiler expands them
 
 typedef void (*kern_t)(float *, int, float);
@@ -95,7 +100,10 @@ int main() {
         {"v_add_f32 (inline constant)", k_add_const, 64}, {"v_pk_fma_f32 (two results each)", k_pk_fma, 64}, {"v_pk_mul_f32", k_pk_mul, 64}, {"v_pk_add_f32", k_pk_add, 64},
         {"v_mov_b32", k_mov, 64}, {"v_and_b32", k_and, 64}, {"v_lshlrev_b32", k_lshl, 64}, {"v_lshl_add_u32", k_lshl_add, 64}, {"v_add3_u32", k_add3, 64},
         {"v_mad_u32_u24", k_mad24, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_min_u32 / v_max_u32", k_min_u32, 64}, {"v_med3_f32", k_med3, 64}, {"v_cvt_f32_u32", k_cvt_u32, 64},
-        {"v_add_u32_sdwa (byte of a source)", k_add_sdwa, 64}, {"v_cmp -> vcc, three v_cndmask on vcc", k_cndmask_vcc2, 64}, {"ds_write_b32 + ds_read_b32 + wait (per pair)", k_lds, 32}, {"a/b (IEEE) + add, compiler's expansion, per division", k_div_chain, 32},
+        {"v_add_u32_sdwa (byte of a source)", k_add_sdwa, 64}, {"v_cmp -> vcc, three v_cndmask on vcc", k_cndmask_vcc2, 64}, {"ds_write_b32 + ds_read_b32 + wait (per pair)", k_lds, 32},
+        {"v_cndmask_b32_e64 with vcc as the mask, chain", k_cndmask_vcc_e64, 64}, {"v_cndmask_b32 (vcc), independent results", k_cndmask_vcc_indep, 64},
+        {"v_cndmask_b32_e64 (SGPR pair), independent results", k_cndmask_sgpr_indep, 64}, {"one v_cndmask_b32 (vcc) among three v_fma_f32", k_fma_vcc_mix, 64},
+        {"v_addc_co_u32 (vcc in and out)", k_addc, 64}, {"a/b (IEEE) + add, compiler's expansion, per division", k_div_chain, 32},
     };
     const double base = run(k_fma, out, rounds);
     printf("8 waves per SIMD, %d rounds of 64 instructions; v_fma_f32: %.3f ms = 1.00\n", rounds, base);
